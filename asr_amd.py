@@ -1,0 +1,14 @@
+"""Import alias: ``import asr_amd`` loads the package that lives in the directory
+``deeplabv3plus-augmented-superresolution_amd/`` (a name Python cannot import directly because
+of the hyphens).  ``asr_amd.model``, ``asr_amd.utils``, ``asr_amd.superresolution_scripts.*``
+mirror the reference's module layout."""
+import importlib.util
+import os
+import sys
+
+_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "deeplabv3plus-augmented-superresolution_amd")
+_spec = importlib.util.spec_from_file_location(__name__, os.path.join(_dir, "__init__.py"),
+                                               submodule_search_locations=[_dir])
+_mod = importlib.util.module_from_spec(_spec)
+sys.modules[__name__] = _mod
+_spec.loader.exec_module(_mod)

@@ -1,0 +1,89 @@
+// Shared host/device helpers for libasr_hip.so (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include "../../include/asr_hip.h"
+
+// ---- error plumbing -------------------------------------------------------------------
+void asr_set_error(const char* fmt, ...);
+
+#define ASR_REQUIRE(cond, ...)                      \
+    do {                                            \
+        if (!(cond)) {                              \
+            asr_set_error(__VA_ARGS__);             \
+            return ASR_ERR_INVALID_ARG;             \
+        }                                           \
+    } while (0)
+
+#define ASR_UNSUPPORTED(cond, ...)                  \
+    do {                                            \
+        if (cond) {                                 \
+            asr_set_error(__VA_ARGS__);             \
+            return ASR_ERR_UNSUPPORTED;             \
+        }                                           \
+    } while (0)
+
+#define ASR_HIP_CHECK(expr)                                                           \
+    do {                                                                              \
+        hipError_t _e = (expr);                                                       \
+        if (_e != hipSuccess) {                                                       \
+            asr_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e),      \
+                          __FILE__, __LINE__);                                        \
+            return ASR_ERR_HIP;                                                       \
+        }                                                                             \
+    } while (0)
+
+#define ASR_LAUNCH_CHECK() ASR_HIP_CHECK(hipGetLastError())
+
+static inline hipStream_t asr_stream(asr_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+static inline int64_t asr_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// ---- device helpers -------------------------------------------------------------------
+#ifdef __HIPCC__
+
+// One flat projective transform (ImageProjectiveTransformV3 parameter vector).
+struct AsrTf8 {
+    float a0, a1, a2, b0, b1, b2, c0, c1;
+};
+
+__device__ __forceinline__ AsrTf8 asr_load_tf(const float* __restrict__ t) {
+    AsrTf8 r;
+    r.a0 = t[0]; r.a1 = t[1]; r.a2 = t[2];
+    r.b0 = t[3]; r.b1 = t[4]; r.b2 = t[5];
+    r.c0 = t[6]; r.c1 = t[7];
+    return r;
+}
+
+// float -> int for a floor()ed coordinate; clamps so that far-out-of-range (or NaN)
+// coordinates become an index every bounds check rejects.
+__device__ __forceinline__ int asr_coord_to_int(float f) {
+    f = fminf(fmaxf(f, -1.0e9f), 1.0e9f);
+    return (f == f) ? (int)f : -1000000000;
+}
+
+// wave64 sum via DPP-free shuffles.
+__device__ __forceinline__ float asr_wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double asr_wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float asr_wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_down(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float asr_wave_min(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_down(v, o, 64));
+    return v;
+}
+
+#endif  // __HIPCC__

@@ -1,0 +1,321 @@
+// Pointwise (1x1) convolution and small dense KxK convolution as an LDS-tiled FP32 MFMA GEMM
+// for gfx950:  Y[m, n] = act( sum_k A[m, k] * W[k, n] + bias[n] ) (+ residual[m, n]).
+//
+// Reference layers served (paths in /root/reference): every Conv2D(.., (1,1)) of model.py --
+// _SepConv_BN pointwise :500-503, _conv2d_same shortcuts :529-541, aspp0 / image_pooling /
+// concat_projection :195-231, feature_projection0 :244-247, logits :303-304 -- and the
+// 3x3 stem conv entry_flow_conv1_2 :155-156 (implicit GEMM, one tap per K-tile).
+//
+// Design (MI355X): v_mfma_f32_32x32x2_f32 (exact f32, 64 FLOP/clk/SIMD).  Block = 4 waves,
+// 128 x {128,64,32} output tile, BK = 32, double-buffered LDS, one barrier per K-tile, next
+// tile's global loads in flight behind the current tile's 64 MFMAs per wave.
+//  * A tile [BM][32] is XOR-swizzled on its 16-byte slots so the per-lane ds_read_b128 of
+//    one row's k-quad is bank-conflict free.
+//  * W is pre-packed once per model into [K/4][Npad][4] (k-quads interleaved) so a lane reads
+//    four consecutive k of one output column with one ds_read_b128; K is padded to 32 and N
+//    to 128 with zeros so the B path needs no predicates.
+//  * The k -> (mfma step, lane half) assignment is a permutation shared by A and B: lane half
+//    h of step t in quad-pair kk holds k = 8*kk + 4*h + t.
+//  * blockIdx -> tile mapping is XCD-aware: the tiles that share an A row-panel get
+//    consecutive logical ids, and logical ids are dealt so that consecutive ones share an XCD
+//    (private L2), using the bijective remap.
+#include "asr_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int BK = 32;
+
+struct PwArgs {
+    const float* x;
+    const float* wp;
+    const float* bias;
+    const float* res;
+    float* y;
+    long long M;
+    int K, N, Npad;
+    int ldx, ldy, ldres;
+    int relu;
+    int tiles_n;
+    // row mapping: output row m = (b, oy, ox) of an h_out x w_out map
+    int taps;  // 1 = pointwise (optionally spatially subsampled), 9 = 3x3 implicit GEMM
+    int cin;   // channels per tap
+    int h_in, w_in, h_out, w_out, stride, pad, dil;
+};
+
+template <int WM, int WN, int TM, int TN, bool CONV>
+__global__ __launch_bounds__(256) void pw_gemm_kernel(PwArgs p) {
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    constexpr int A_F4 = BM / 32;  // float4 staged per thread per K-tile
+    constexpr int B_F4 = BN / 32;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* const sA = smem;                // [2][BM*32]
+    float* const sB = smem + 2 * BM * BK;  // [2][32*BN]
+
+    // XCD-aware bijective remap of the workgroup id (speed only)
+    const int nwg = gridDim.x, orig = blockIdx.x;
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
+    const int lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+    const int tile_m = lid / p.tiles_n, tile_n = lid % p.tiles_n;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int l32 = lane & 31, hh = lane >> 5;
+
+    // ---- per-thread A staging coordinates (fixed over the K loop) --------------------------
+    const int a_c4 = tid & 7;
+    const float* a_base[A_F4];
+    int a_oy[A_F4], a_ox[A_F4];
+#pragma unroll
+    for (int i = 0; i < A_F4; ++i) {
+        const int row = (tid >> 3) + 32 * i;
+        const long long m = (long long)tile_m * BM + row;
+        a_base[i] = nullptr;
+        a_oy[i] = 0;
+        a_ox[i] = 0;
+        if (m < p.M) {
+            if (p.h_out > 0) {  // spatial mapping
+                const int ox = (int)(m % p.w_out);
+                const long long t = m / p.w_out;
+                const int oy = (int)(t % p.h_out);
+                const long long b = t / p.h_out;
+                if (CONV) {
+                    a_oy[i] = oy * p.stride - p.pad;
+                    a_ox[i] = ox * p.stride - p.pad;
+                    a_base[i] = p.x + b * (long long)p.h_in * p.w_in * p.ldx;
+                } else {
+                    a_base[i] = p.x + ((b * p.h_in + (long long)oy * p.stride) * p.w_in + (long long)ox * p.stride) * p.ldx;
+                }
+            } else {
+                a_base[i] = p.x + m * p.ldx;
+            }
+        }
+    }
+    const float* b_base = p.wp + ((long long)tile_n * BN) * 4;
+
+    f32x4 ra[A_F4], rb[B_F4];
+
+    auto load_tile = [&](int kt) {
+        const int k0 = kt * BK;
+#pragma unroll
+        for (int i = 0; i < A_F4; ++i) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (CONV) {
+                const int tap = k0 / p.cin, coff = k0 - tap * p.cin;
+                const int dy = tap / 3, dx = tap - dy * 3;
+                const int iy = a_oy[i] + dy * p.dil, ix = a_ox[i] + dx * p.dil;
+                const int k = coff + a_c4 * 4;
+                if (a_base[i] && iy >= 0 && iy < p.h_in && ix >= 0 && ix < p.w_in && k < p.cin)
+                    v = *reinterpret_cast<const f32x4*>(a_base[i] + ((long long)iy * p.w_in + ix) * p.ldx + k);
+            } else {
+                const int k = k0 + a_c4 * 4;
+                if (a_base[i] && k < p.K) v = *reinterpret_cast<const f32x4*>(a_base[i] + k);
+            }
+            ra[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < B_F4; ++i) {
+            const int qq = tid + 256 * i;
+            const int kq = qq / BN, n = qq % BN;
+            rb[i] = *reinterpret_cast<const f32x4*>(b_base + ((long long)(k0 / 4 + kq) * p.Npad + n) * 4);
+        }
+    };
+    auto store_tile = [&](int buf) {
+        float* dA = sA + buf * BM * BK;
+        float* dB = sB + buf * BK * BN;
+#pragma unroll
+        for (int i = 0; i < A_F4; ++i) {
+            const int row = (tid >> 3) + 32 * i;
+            *reinterpret_cast<f32x4*>(dA + (row * 8 + (a_c4 ^ ((row >> 1) & 7))) * 4) = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < B_F4; ++i) {
+            const int qq = tid + 256 * i;
+            *reinterpret_cast<f32x4*>(dB + qq * 4) = rb[i];
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int KT = (p.K + BK - 1) / BK;
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+
+    for (int kt = 0; kt < KT; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < KT) load_tile(kt + 1);
+        const float* cA = sA + buf * BM * BK;
+        const float* cB = sB + buf * BK * BN;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const int slot = 2 * kk + hh;
+            f32x4 a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int row = (wm * TM + i) * 32 + l32;
+                a[i] = *reinterpret_cast<const f32x4*>(cA + (row * 8 + (slot ^ ((row >> 1) & 7))) * 4);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int col = (wn * TN + j) * 32 + l32;
+                b[j] = *reinterpret_cast<const f32x4*>(cB + (slot * BN + col) * 4);
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][t], b[j][t], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < KT) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: bias, ReLU, residual, store ------------------------------------------------
+    // C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = tile_n * BN + (wn * TN + j) * 32 + l32;
+        if (n >= p.N) continue;
+        const float bv = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const long long m0 = (long long)tile_m * BM + (wm * TM + i) * 32 + 4 * hh;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const long long m = m0 + (e & 3) + 8 * (e >> 2);
+                if (m < p.M) {
+                    float v = acc[i][j][e] + bv;
+                    if (p.relu) v = fmaxf(v, 0.f);
+                    if (p.res) v += p.res[m * p.ldres + n];
+                    p.y[m * p.ldy + n] = v;
+                }
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ wp, int K, int N,
+                                                           int Kpad, int Npad) {
+    const long long total = (long long)Kpad * Npad;
+    for (long long o = (long long)blockIdx.x * 256 + threadIdx.x; o < total; o += (long long)gridDim.x * 256) {
+        const int kr = (int)(o & 3);
+        const long long t = o >> 2;
+        const int n = (int)(t % Npad);
+        const int k = (int)(t / Npad) * 4 + kr;
+        wp[o] = (k < K && n < N) ? w[(long long)k * N + n] : 0.f;
+    }
+}
+
+template <int WM, int WN, int TM, int TN, bool CONV>
+int launch(const PwArgs& a, hipStream_t s) {
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    PwArgs p = a;
+    p.tiles_n = (int)asr_cdiv(p.N, BN);
+    const long long tiles_m = asr_cdiv(p.M, BM);
+    const long long nwg = tiles_m * p.tiles_n;
+    if (nwg > 0x7fffffffLL) {
+        asr_set_error("asr_pwconv_mfma_f32: grid too large (%lld workgroups)", nwg);
+        return ASR_ERR_INVALID_ARG;
+    }
+    const size_t lds = sizeof(float) * 2 * (BM * BK + BK * BN);
+    auto kern = pw_gemm_kernel<WM, WN, TM, TN, CONV>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        ASR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(256), lds, s, p);
+    ASR_LAUNCH_CHECK();
+    return ASR_OK;
+}
+
+template <bool CONV>
+int dispatch(const PwArgs& a, hipStream_t s) {
+    if (a.N <= 32) return launch<4, 1, 1, 1, CONV>(a, s);
+    if (a.N <= 64) return launch<2, 2, 2, 1, CONV>(a, s);
+    return launch<2, 2, 2, 2, CONV>(a, s);
+}
+
+inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+}  // namespace
+
+extern "C" size_t asr_pwconv_packed_floats(int k, int n) {
+    if (k <= 0 || n <= 0) return 0;
+    return (size_t)round_up(k, BK) * (size_t)round_up(n, 128);
+}
+
+extern "C" int asr_pwconv_pack_weights_f32(const float* w_kn, float* w_packed, int k, int n, asr_stream_t stream) {
+    ASR_REQUIRE(w_kn && w_packed, "asr_pwconv_pack_weights_f32: null pointer");
+    ASR_REQUIRE(k > 0 && n > 0, "asr_pwconv_pack_weights_f32: bad shape k=%d n=%d", k, n);
+    const int Kpad = round_up(k, BK), Npad = round_up(n, 128);
+    const long long total = (long long)Kpad * Npad;
+    const int grid = (int)(asr_cdiv(total, 256) < 4096 ? asr_cdiv(total, 256) : 4096);
+    hipLaunchKernelGGL(pack_weights_kernel, dim3(grid), dim3(256), 0, asr_stream(stream), w_kn, w_packed, k, n, Kpad, Npad);
+    ASR_LAUNCH_CHECK();
+    return ASR_OK;
+}
+
+static int check_common(const char* fn, const float* x, const float* wp, float* y, long long m, int k, int n, int ldx, int ldy,
+                        const float* res, int ldres) {
+    ASR_REQUIRE(x && wp && y, "%s: null pointer", fn);
+    ASR_REQUIRE(m > 0 && k > 0 && n > 0, "%s: bad shape m=%lld k=%d n=%d", fn, m, k, n);
+    ASR_REQUIRE(ldy >= n && (!res || ldres >= n), "%s: ldy/ldres smaller than n", fn);
+    ASR_UNSUPPORTED((ldx & 3) || (reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(wp) & 15),
+                    "%s: x rows must be 16-byte aligned (ldx %% 4 == 0, base aligned)", fn);
+    return ASR_OK;
+}
+
+extern "C" int asr_pwconv_mfma_f32(const float* x, const float* w_packed, const float* bias, const float* residual, float* y,
+                                   int64_t m, int k, int n, int ldx, int ldy, int ldres, int relu, int sub_stride,
+                                   int h_in, int w_in, asr_stream_t stream) {
+    int rc = check_common("asr_pwconv_mfma_f32", x, w_packed, y, m, k, n, ldx, ldy, residual, ldres);
+    if (rc != ASR_OK) return rc;
+    ASR_REQUIRE(ldx >= k, "asr_pwconv_mfma_f32: ldx < k");
+    ASR_UNSUPPORTED(k & 3, "asr_pwconv_mfma_f32: k must be a multiple of 4 (got %d)", k);
+    PwArgs a{};
+    a.x = x; a.wp = w_packed; a.bias = bias; a.res = residual; a.y = y;
+    a.M = m; a.K = k; a.N = n; a.Npad = round_up(n, 128);
+    a.ldx = ldx; a.ldy = ldy; a.ldres = ldres; a.relu = relu;
+    a.taps = 1; a.cin = k; a.stride = 1; a.pad = 0; a.dil = 1;
+    if (sub_stride > 1) {
+        ASR_REQUIRE(h_in > 0 && w_in > 0, "asr_pwconv_mfma_f32: h_in/w_in required with sub_stride");
+        a.h_in = h_in; a.w_in = w_in; a.stride = sub_stride;
+        a.h_out = (h_in + sub_stride - 1) / sub_stride;
+        a.w_out = (w_in + sub_stride - 1) / sub_stride;
+        ASR_REQUIRE(m % ((long long)a.h_out * a.w_out) == 0, "asr_pwconv_mfma_f32: m is not a whole number of %dx%d maps",
+                    a.h_out, a.w_out);
+    }
+    return dispatch<false>(a, asr_stream(stream));
+}
+
+extern "C" int asr_conv3x3_mfma_f32(const float* x, const float* w_packed, const float* bias, float* y, int batch, int h_in,
+                                    int w_in, int cin, int cout, int stride, int pad, int dil, int h_out, int w_out, int ldx,
+                                    int ldy, int relu, asr_stream_t stream) {
+    const long long m = (long long)batch * h_out * w_out;
+    int rc = check_common("asr_conv3x3_mfma_f32", x, w_packed, y, m, 9 * cin, cout, ldx, ldy, nullptr, 0);
+    if (rc != ASR_OK) return rc;
+    ASR_REQUIRE(batch > 0 && h_in > 0 && w_in > 0 && h_out > 0 && w_out > 0 && stride > 0 && dil > 0 && pad >= 0,
+                "asr_conv3x3_mfma_f32: bad geometry");
+    ASR_UNSUPPORTED(cin % BK, "asr_conv3x3_mfma_f32: cin must be a multiple of %d (got %d)", BK, cin);
+    ASR_REQUIRE(ldx >= cin, "asr_conv3x3_mfma_f32: ldx < cin");
+    PwArgs a{};
+    a.x = x; a.wp = w_packed; a.bias = bias; a.res = nullptr; a.y = y;
+    a.M = m; a.K = 9 * cin; a.N = cout; a.Npad = round_up(cout, 128);
+    a.ldx = ldx; a.ldy = ldy; a.ldres = 0; a.relu = relu;
+    a.taps = 9; a.cin = cin; a.h_in = h_in; a.w_in = w_in; a.h_out = h_out; a.w_out = w_out;
+    a.stride = stride; a.pad = pad; a.dil = dil;
+    return dispatch<true>(a, asr_stream(stream));
+}

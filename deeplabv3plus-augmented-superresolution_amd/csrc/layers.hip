@@ -1,0 +1,151 @@
+// Remaining DeepLabV3+ layers as NHWC float32 kernels (gfx950):
+//   asr_conv3x3_direct_f32   dense 3x3 for tiny Cin (entry_flow_conv1_1: 3 -> 32, stride 2, model.py:150-151)
+//   asr_gap_f32              GlobalAveragePooling2D(keepdims) (model.py:196-197)
+//   asr_resize_bilinear_f32  Resizing(bilinear) = tf.image.resize half-pixel (model.py:109-110,204-205,241-242)
+// All HBM-bound; lanes own 4 consecutive channels so stores are whole 16-byte pieces of a pixel row.
+#include "asr_common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+// ---- dense 3x3, small cin: weights [3][3][cin][cout] in LDS, thread = (pixel, 4 output channels) ----
+__global__ __launch_bounds__(256) void conv3x3_direct_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                             const float* __restrict__ bias, float* __restrict__ y,
+                                                             int batch, int h_in, int w_in, int cin, int cout, int stride,
+                                                             int pad_top, int pad_left, int h_out, int w_out, int ldx,
+                                                             int ldy, int relu) {
+    extern __shared__ __attribute__((aligned(16))) float sw[];  // 9*cin*cout
+    const int nw = 9 * cin * cout;
+    for (int i = threadIdx.x; i < nw; i += 256) sw[i] = w[i];
+    __syncthreads();
+    const int co4n = cout >> 2;
+    const long long total = (long long)batch * h_out * w_out * co4n;
+    for (long long o = (long long)blockIdx.x * 256 + threadIdx.x; o < total; o += (long long)gridDim.x * 256) {
+        const int co4 = (int)(o % co4n);
+        long long t = o / co4n;
+        const int ox = (int)(t % w_out); t /= w_out;
+        const int oy = (int)(t % h_out);
+        const long long b = t / h_out;
+        const float* xin = x + b * h_in * w_in * ldx;
+        f32x4 acc = *reinterpret_cast<const f32x4*>(bias + co4 * 4);
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = oy * stride - pad_top + ky;
+            if (iy < 0 || iy >= h_in) continue;
+            for (int kx = 0; kx < 3; ++kx) {
+                const int ix = ox * stride - pad_left + kx;
+                if (ix < 0 || ix >= w_in) continue;
+                const float* px = xin + ((long long)iy * w_in + ix) * ldx;
+                const float* pw = sw + ((ky * 3 + kx) * cin) * cout + co4 * 4;
+                for (int ci = 0; ci < cin; ++ci) {
+                    const float v = px[ci];
+                    acc += v * *reinterpret_cast<const f32x4*>(pw + ci * cout);
+                }
+            }
+        }
+        if (relu) { acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f); }
+        *reinterpret_cast<f32x4*>(y + ((b * h_out + oy) * w_out + ox) * ldy + co4 * 4) = acc;
+    }
+}
+
+// ---- global average pool: block = 64 channel-quads x 4 pixel groups ----------------------------
+__global__ __launch_bounds__(256) void gap_kernel(const float* __restrict__ x, float* __restrict__ y, int hw, int c, int ldx) {
+    __shared__ f32x4 part[4][64];
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int c4 = blockIdx.x * 64 + lane;
+    const int b = blockIdx.y;
+    const bool ok = c4 * 4 < c;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (ok) {
+        const float* p = x + (long long)b * hw * ldx + c4 * 4;
+        for (int i = grp; i < hw; i += 4) acc += *reinterpret_cast<const f32x4*>(p + (long long)i * ldx);
+    }
+    part[grp][lane] = acc;
+    __syncthreads();
+    if (grp == 0 && ok) {
+        f32x4 s = part[0][lane] + part[1][lane];
+        s += part[2][lane];
+        s += part[3][lane];
+        const float inv = 1.0f / (float)hw;
+        *reinterpret_cast<f32x4*>(y + (long long)b * c + c4 * 4) = s * inv;
+    }
+}
+
+// ---- bilinear resize, TF2 half-pixel centres ------------------------------------------------------
+__global__ __launch_bounds__(256) void resize_bilinear_kernel(const float* __restrict__ x, float* __restrict__ y, int batch,
+                                                              int h_in, int w_in, int c, int h_out, int w_out, int ldx,
+                                                              int ldy, float scale_y, float scale_x) {
+    const int c4n = c >> 2;
+    const long long total = (long long)batch * h_out * w_out * c4n;
+    for (long long o = (long long)blockIdx.x * 256 + threadIdx.x; o < total; o += (long long)gridDim.x * 256) {
+        const int c4 = (int)(o % c4n);
+        long long t = o / c4n;
+        const int ox = (int)(t % w_out); t /= w_out;
+        const int oy = (int)(t % h_out);
+        const long long b = t / h_out;
+        const float py = ((float)oy + 0.5f) * scale_y - 0.5f, px = ((float)ox + 0.5f) * scale_x - 0.5f;
+        const float fy = floorf(py), fx = floorf(px);
+        const int ylo = max((int)fy, 0), yhi = min((int)ceilf(py), h_in - 1);
+        const int xlo = max((int)fx, 0), xhi = min((int)ceilf(px), w_in - 1);
+        const float ty = py - fy, tx = px - fx;
+        const float* base = x + b * h_in * w_in * ldx + c4 * 4;
+        const f32x4 tl = *reinterpret_cast<const f32x4*>(base + ((long long)ylo * w_in + xlo) * ldx);
+        const f32x4 tr = *reinterpret_cast<const f32x4*>(base + ((long long)ylo * w_in + xhi) * ldx);
+        const f32x4 bl = *reinterpret_cast<const f32x4*>(base + ((long long)yhi * w_in + xlo) * ldx);
+        const f32x4 br = *reinterpret_cast<const f32x4*>(base + ((long long)yhi * w_in + xhi) * ldx);
+        const f32x4 top = tl + (tr - tl) * tx;
+        const f32x4 bot = bl + (br - bl) * tx;
+        *reinterpret_cast<f32x4*>(y + ((b * h_out + oy) * w_out + ox) * ldy + c4 * 4) = top + (bot - top) * ty;
+    }
+}
+
+int cap_grid(long long total) {
+    const long long g = asr_cdiv(total, 256);
+    return (int)(g < 8192 ? (g > 0 ? g : 1) : 8192);
+}
+
+}  // namespace
+
+extern "C" int asr_conv3x3_direct_f32(const float* x, const float* w, const float* bias, float* y, int batch, int h_in,
+                                      int w_in, int cin, int cout, int stride, int pad_top, int pad_left, int h_out,
+                                      int w_out, int ldx, int ldy, int relu, asr_stream_t stream) {
+    ASR_REQUIRE(x && w && bias && y, "asr_conv3x3_direct_f32: null pointer");
+    ASR_REQUIRE(batch > 0 && h_in > 0 && w_in > 0 && cin > 0 && cout > 0 && stride > 0 && h_out > 0 && w_out > 0 &&
+                    pad_top >= 0 && pad_left >= 0 && ldx >= cin && ldy >= cout,
+                "asr_conv3x3_direct_f32: bad geometry");
+    ASR_UNSUPPORTED((cout & 3) || (ldy & 3) || 9 * cin * cout > 12288,
+                    "asr_conv3x3_direct_f32: cout %% 4 == 0, ldy %% 4 == 0 and 9*cin*cout <= 12288 required (cin=%d cout=%d)", cin, cout);
+    ASR_UNSUPPORTED((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(bias)) & 15,
+                    "asr_conv3x3_direct_f32: y and bias must be 16-byte aligned");
+    const long long total = (long long)batch * h_out * w_out * (cout >> 2);
+    hipLaunchKernelGGL(conv3x3_direct_kernel, dim3(cap_grid(total)), dim3(256), sizeof(float) * 9 * cin * cout,
+                       asr_stream(stream), x, w, bias, y, batch, h_in, w_in, cin, cout, stride, pad_top, pad_left, h_out,
+                       w_out, ldx, ldy, relu);
+    ASR_LAUNCH_CHECK();
+    return ASR_OK;
+}
+
+extern "C" int asr_gap_f32(const float* x, float* y, int batch, int hw, int c, int ldx, asr_stream_t stream) {
+    ASR_REQUIRE(x && y, "asr_gap_f32: null pointer");
+    ASR_REQUIRE(batch > 0 && batch <= 65535 && hw > 0 && c > 0 && ldx >= c, "asr_gap_f32: bad shape");
+    ASR_UNSUPPORTED((c & 3) || (ldx & 3) || ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15),
+                    "asr_gap_f32: c, ldx multiples of 4 and 16-byte aligned pointers required");
+    hipLaunchKernelGGL(gap_kernel, dim3((unsigned)asr_cdiv(c, 256), batch), dim3(256), 0, asr_stream(stream), x, y, hw, c, ldx);
+    ASR_LAUNCH_CHECK();
+    return ASR_OK;
+}
+
+extern "C" int asr_resize_bilinear_f32(const float* x, float* y, int batch, int h_in, int w_in, int c, int h_out, int w_out,
+                                       int ldx, int ldy, asr_stream_t stream) {
+    ASR_REQUIRE(x && y, "asr_resize_bilinear_f32: null pointer");
+    ASR_REQUIRE(batch > 0 && h_in > 0 && w_in > 0 && c > 0 && h_out > 0 && w_out > 0 && ldx >= c && ldy >= c,
+                "asr_resize_bilinear_f32: bad shape");
+    ASR_UNSUPPORTED((c & 3) || (ldx & 3) || (ldy & 3) || ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15),
+                    "asr_resize_bilinear_f32: c, ldx, ldy multiples of 4 and 16-byte aligned pointers required");
+    const long long total = (long long)batch * h_out * w_out * (c >> 2);
+    const float sy = (float)h_in / (float)h_out, sx = (float)w_in / (float)w_out;
+    hipLaunchKernelGGL(resize_bilinear_kernel, dim3(cap_grid(total)), dim3(256), 0, asr_stream(stream), x, y, batch, h_in,
+                       w_in, c, h_out, w_out, ldx, ldy, sy, sx);
+    ASR_LAUNCH_CHECK();
+    return ASR_OK;
+}

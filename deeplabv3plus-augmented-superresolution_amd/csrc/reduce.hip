@@ -1,0 +1,223 @@
+// Output-processing (OPM), thresholding and IoU counting kernels (gfx950).
+//
+// Reference (paths in /root/reference):
+//   utils.py:115-119                                    create_mask (argmax)
+//   superresolution_scripts/augmentation_utils.py:80-115  OPM modes argmax / slice / slice_max
+//   superresolution_scripts/superres_utils.py:56-62,118-139  min_max_normalization, threshold_image
+//   utils.py:180-204                                    single_class_IOU (integer counts)
+// All of these are HBM-bound single passes; per-segment reductions use wave shuffles and one
+// block per segment so the results are deterministic.
+#include "asr_common.h"
+
+namespace {
+
+// ---- per-segment min / max ------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void minmax_kernel(const float* __restrict__ x, float* __restrict__ out,
+                                                      int64_t per_seg) {
+    __shared__ float smin[16], smax[16];
+    const float* p = x + (int64_t)blockIdx.x * per_seg;
+    float mn = INFINITY, mx = -INFINITY;
+    for (int64_t i = threadIdx.x; i < per_seg; i += 1024) {
+        const float v = p[i];
+        mn = fminf(mn, v);
+        mx = fmaxf(mx, v);
+    }
+    mn = asr_wave_min(mn);
+    mx = asr_wave_max(mx);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) { smin[wave] = mn; smax[wave] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < 16; ++i) { mn = fminf(mn, smin[i]); mx = fmaxf(mx, smax[i]); }
+        out[blockIdx.x * 2 + 0] = mn;
+        out[blockIdx.x * 2 + 1] = mx;
+    }
+}
+
+// ---- argmax over the class axis (first maximum wins, like tf.argmax) --------------------------
+__device__ __forceinline__ int argmax_row(const float* __restrict__ row, int classes) {
+    float best = row[0];
+    int arg = 0;
+    for (int c = 1; c < classes; ++c) {
+        const float v = row[c];
+        if (v > best) { best = v; arg = c; }
+    }
+    return arg;
+}
+
+__global__ __launch_bounds__(256) void argmax_kernel(const float* __restrict__ logits, int32_t* __restrict__ out,
+                                                     int64_t pixels, int classes) {
+    for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < pixels; p += (int64_t)gridDim.x * 256)
+        out[p] = argmax_row(logits + p * classes, classes);
+}
+
+__global__ __launch_bounds__(256) void opm_argmax_kernel(const float* __restrict__ logits, float* __restrict__ out,
+                                                         int64_t pixels, int classes, int class_id) {
+    for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < pixels; p += (int64_t)gridDim.x * 256)
+        out[p] = (argmax_row(logits + p * classes, classes) == class_id) ? (float)class_id : 0.0f;
+}
+
+__global__ __launch_bounds__(256) void opm_slice_max_kernel(const float* __restrict__ logits, float* __restrict__ cls,
+                                                            float* __restrict__ mx, int64_t pixels, int classes,
+                                                            int class_id) {
+    for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < pixels; p += (int64_t)gridDim.x * 256) {
+        const float* row = logits + p * classes;
+        float best = -INFINITY;
+        for (int c = 0; c < classes; ++c)
+            if (c != class_id) best = fmaxf(best, row[c]);
+        cls[p] = row[class_id];
+        mx[p] = best;
+    }
+}
+
+// slice OPM: class logit min-max normalised by the per-copy global min/max (seg_minmax[copy])
+__global__ __launch_bounds__(256) void opm_slice_kernel(const float* __restrict__ logits, float* __restrict__ out,
+                                                        const float* __restrict__ seg_minmax, int64_t pixels_per_copy,
+                                                        int classes, int class_id, float new_min, float new_max) {
+    const int copy = blockIdx.y;
+    const float mn = seg_minmax[copy * 2 + 0], mxv = seg_minmax[copy * 2 + 1];
+    const float den = ((mxv - mn) != 0.0f) ? (mxv - mn) : 1.0f;
+    const float span = new_max - new_min;
+    const float* base = logits + (int64_t)copy * pixels_per_copy * classes;
+    float* o = out + (int64_t)copy * pixels_per_copy;
+    for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < pixels_per_copy; p += (int64_t)gridDim.x * 256) {
+        const float num = (base[p * classes + class_id] - mn) * span;
+        o[p] = new_min + num / den;
+    }
+}
+
+// ---- threshold_image -----------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void threshold_kernel(const float* __restrict__ img, const float* __restrict__ th_mask,
+                                                        const float* __restrict__ seg_minmax, int32_t* __restrict__ out,
+                                                        int64_t per_seg, float th_factor, int th_value) {
+    const int seg = blockIdx.y;
+    const float* p = img + (int64_t)seg * per_seg;
+    int32_t* o = out + (int64_t)seg * per_seg;
+    if (th_mask) {
+        const float* t = th_mask + (int64_t)seg * per_seg;
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < per_seg; i += (int64_t)gridDim.x * 256)
+            o[i] = (p[i] >= t[i]) ? th_value : 0;
+    } else {
+        const float th = seg_minmax[seg * 2 + 1] * th_factor;
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < per_seg; i += (int64_t)gridDim.x * 256)
+            o[i] = (p[i] > th) ? th_value : 0;
+    }
+}
+
+// ---- IoU counts: counts[seg] = {inter_c, union_c, inter_bg, union_bg} ------------------------------
+__global__ __launch_bounds__(256) void iou_counts_kernel(const int32_t* __restrict__ truth, const int32_t* __restrict__ pred,
+                                                         unsigned long long* __restrict__ counts, int64_t per_seg,
+                                                         int class_id, int include_bg) {
+    const int seg = blockIdx.y;
+    const int32_t* t = truth + (int64_t)seg * per_seg;
+    const int32_t* q = pred + (int64_t)seg * per_seg;
+    unsigned int ic = 0, uc = 0, ib = 0, ub = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < per_seg; i += (int64_t)gridDim.x * 256) {
+        int tv = t[i];
+        const int pv = q[i];
+        if (include_bg && tv != class_id) tv = 0;  // utils.py:188-190
+        const bool tc = tv == class_id, pc = pv == class_id;
+        ic += (tc && pc); uc += (tc || pc);
+        const bool tb = tv == 0, pb = pv == 0;
+        ib += (tb && pb); ub += (tb || pb);
+    }
+    auto wsum = [](unsigned int v) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+        return v;
+    };
+    ic = wsum(ic); uc = wsum(uc); ib = wsum(ib); ub = wsum(ub);
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(counts + seg * 4 + 0, (unsigned long long)ic);
+        atomicAdd(counts + seg * 4 + 1, (unsigned long long)uc);
+        atomicAdd(counts + seg * 4 + 2, (unsigned long long)ib);
+        atomicAdd(counts + seg * 4 + 3, (unsigned long long)ub);
+    }
+}
+
+int stream_grid(int64_t n) {
+    int64_t g = asr_cdiv(n, 256);
+    return (int)(g < 2048 ? (g > 0 ? g : 1) : 2048);
+}
+
+}  // namespace
+
+extern "C" int asr_minmax_f32(const float* x, float* out_minmax, int64_t per_segment, int segments, asr_stream_t stream) {
+    ASR_REQUIRE(x && out_minmax, "asr_minmax_f32: null pointer");
+    ASR_REQUIRE(per_segment > 0 && segments > 0, "asr_minmax_f32: empty input (per_segment=%lld segments=%d)",
+                (long long)per_segment, segments);
+    hipLaunchKernelGGL(minmax_kernel, dim3(segments), dim3(1024), 0, asr_stream(stream), x, out_minmax, per_segment);
+    ASR_LAUNCH_CHECK();
+    return ASR_OK;
+}
+
+extern "C" int asr_argmax_i32(const float* logits, int32_t* out, int64_t pixels, int classes, asr_stream_t stream) {
+    ASR_REQUIRE(logits && out, "asr_argmax_i32: null pointer");
+    ASR_REQUIRE(pixels > 0 && classes > 0, "asr_argmax_i32: bad shape");
+    hipLaunchKernelGGL(argmax_kernel, dim3(stream_grid(pixels)), dim3(256), 0, asr_stream(stream), logits, out, pixels, classes);
+    ASR_LAUNCH_CHECK();
+    return ASR_OK;
+}
+
+extern "C" int asr_opm_argmax_f32(const float* logits, float* class_mask, int64_t pixels, int classes, int class_id,
+                                  asr_stream_t stream) {
+    ASR_REQUIRE(logits && class_mask, "asr_opm_argmax_f32: null pointer");
+    ASR_REQUIRE(pixels > 0 && classes > 0 && class_id >= 0 && class_id < classes, "asr_opm_argmax_f32: bad shape/class");
+    hipLaunchKernelGGL(opm_argmax_kernel, dim3(stream_grid(pixels)), dim3(256), 0, asr_stream(stream), logits, class_mask,
+                       pixels, classes, class_id);
+    ASR_LAUNCH_CHECK();
+    return ASR_OK;
+}
+
+extern "C" int asr_opm_slice_max_f32(const float* logits, float* class_mask, float* max_mask, int64_t pixels, int classes,
+                                     int class_id, asr_stream_t stream) {
+    ASR_REQUIRE(logits && class_mask && max_mask, "asr_opm_slice_max_f32: null pointer");
+    ASR_REQUIRE(pixels > 0 && classes > 1 && class_id >= 0 && class_id < classes, "asr_opm_slice_max_f32: bad shape/class");
+    hipLaunchKernelGGL(opm_slice_max_kernel, dim3(stream_grid(pixels)), dim3(256), 0, asr_stream(stream), logits,
+                       class_mask, max_mask, pixels, classes, class_id);
+    ASR_LAUNCH_CHECK();
+    return ASR_OK;
+}
+
+extern "C" int asr_opm_slice_f32(const float* logits, float* class_mask, float* minmax_ws, int copies,
+                                 int64_t pixels_per_copy, int classes, int class_id, float new_min, float new_max,
+                                 asr_stream_t stream) {
+    ASR_REQUIRE(logits && class_mask && minmax_ws, "asr_opm_slice_f32: null pointer");
+    ASR_REQUIRE(copies > 0 && copies <= 65535 && pixels_per_copy > 0 && classes > 0 && class_id >= 0 && class_id < classes,
+                "asr_opm_slice_f32: bad shape/class");
+    int rc = asr_minmax_f32(logits, minmax_ws, pixels_per_copy * classes, copies, stream);
+    if (rc != ASR_OK) return rc;
+    hipLaunchKernelGGL(opm_slice_kernel, dim3(stream_grid(pixels_per_copy), copies), dim3(256), 0, asr_stream(stream),
+                       logits, class_mask, minmax_ws, pixels_per_copy, classes, class_id, new_min, new_max);
+    ASR_LAUNCH_CHECK();
+    return ASR_OK;
+}
+
+extern "C" int asr_threshold_f32(const float* image, const float* th_mask, float* minmax_ws, int32_t* out,
+                                 int64_t per_segment, int segments, float th_factor, int th_value,
+                                 asr_stream_t stream) {
+    ASR_REQUIRE(image && out, "asr_threshold_f32: null pointer");
+    ASR_REQUIRE(per_segment > 0 && segments > 0 && segments <= 65535, "asr_threshold_f32: bad shape");
+    if (!th_mask) {
+        ASR_REQUIRE(minmax_ws, "asr_threshold_f32: minmax workspace required without th_mask");
+        int rc = asr_minmax_f32(image, minmax_ws, per_segment, segments, stream);
+        if (rc != ASR_OK) return rc;
+    }
+    hipLaunchKernelGGL(threshold_kernel, dim3(stream_grid(per_segment), segments), dim3(256), 0, asr_stream(stream),
+                       image, th_mask, minmax_ws, out, per_segment, th_factor, th_value);
+    ASR_LAUNCH_CHECK();
+    return ASR_OK;
+}
+
+extern "C" int asr_iou_counts_i32(const int32_t* truth, const int32_t* pred, int64_t* counts, int64_t per_segment,
+                                  int segments, int class_id, int include_bg, asr_stream_t stream) {
+    ASR_REQUIRE(truth && pred && counts, "asr_iou_counts_i32: null pointer");
+    ASR_REQUIRE(per_segment > 0 && segments > 0 && segments <= 65535, "asr_iou_counts_i32: bad shape");
+    hipStream_t s = asr_stream(stream);
+    ASR_HIP_CHECK(hipMemsetAsync(counts, 0, sizeof(int64_t) * 4 * segments, s));
+    hipLaunchKernelGGL(iou_counts_kernel, dim3(stream_grid(per_segment) > 256 ? 256 : stream_grid(per_segment), segments),
+                       dim3(256), 0, s, truth, pred, reinterpret_cast<unsigned long long*>(counts), per_segment, class_id,
+                       include_bg);
+    ASR_LAUNCH_CHECK();
+    return ASR_OK;
+}

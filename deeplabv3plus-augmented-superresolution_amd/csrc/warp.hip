@@ -1,0 +1,116 @@
+// Affine / projective warps of NHWC float32 images (gfx950).
+//   asr_warp_affine_f32    : one ImageProjectiveTransformV3 pass (BILINEAR, zero fill)
+//   asr_augment_copies_f32 : translate(rotate(tile(image))) fused, never materialising the
+//                            tiled or rotated stacks (augmentation_utils.py:11-27)
+// HBM-bound gather kernels: the shared source image stays cache resident, each output
+// element is written exactly once with lane-contiguous stores.
+#include "asr_warp_device.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+
+// ---- generic single-stage warp ----------------------------------------------------------
+// One thread per output pixel, all C channels (runtime C).
+__global__ __launch_bounds__(kThreads) void warp_affine_kernel(
+    const float* __restrict__ src, float* __restrict__ dst, const float* __restrict__ tfs,
+    int n, int src_batched, int tf_batched, int h_in, int w_in, int h_out, int w_out, int c) {
+    const int64_t total = (int64_t)n * h_out * w_out;
+    for (int64_t p = (int64_t)blockIdx.x * kThreads + threadIdx.x; p < total;
+         p += (int64_t)gridDim.x * kThreads) {
+        const int x = (int)(p % w_out);
+        const int y = (int)((p / w_out) % h_out);
+        const int b = (int)(p / ((int64_t)w_out * h_out));
+        const AsrTf8 t = asr_load_tf(tfs + (tf_batched ? (int64_t)b * 8 : 0));
+        const float* img = src + (src_batched ? (int64_t)b * h_in * w_in * c : 0);
+        float ix, iy;
+        const bool ok = asr_tf_map(t, (float)x, (float)y, ix, iy);
+        float* o = dst + p * c;
+        for (int ch = 0; ch < c; ++ch) {
+            auto rd = [&](int yy, int xx) -> float {
+                return (yy >= 0 && yy < h_in && xx >= 0 && xx < w_in)
+                           ? img[((int64_t)yy * w_in + xx) * c + ch]
+                           : 0.0f;
+            };
+            o[ch] = ok ? asr_tf_bilinear(rd, ix, iy) : 0.0f;
+        }
+    }
+}
+
+// ---- fused rotate -> translate from one shared source -----------------------------------
+// out[n,y,x,:] = bilinear_T( R_n ) where R_n(yr,xr,:) = bilinear_R(image) for in-bounds
+// integer (yr,xr) and 0 outside: exactly the two sequential resamplings of the reference.
+template <int C>
+__global__ __launch_bounds__(kThreads) void augment_copies_kernel(
+    const float* __restrict__ image, float* __restrict__ copies,
+    const float* __restrict__ rot_tf, const float* __restrict__ trans_tf, int n, int h, int w) {
+    const int64_t total = (int64_t)n * h * w;
+    for (int64_t p = (int64_t)blockIdx.x * kThreads + threadIdx.x; p < total;
+         p += (int64_t)gridDim.x * kThreads) {
+        const int x = (int)(p % w);
+        const int y = (int)((p / w) % h);
+        const int b = (int)(p / ((int64_t)w * h));
+        const AsrTf8 tr = asr_load_tf(rot_tf + (int64_t)b * 8);
+        const AsrTf8 tt = asr_load_tf(trans_tf + (int64_t)b * 8);
+        float out[C];
+        float ix, iy;
+        const bool ok = asr_tf_map(tt, (float)x, (float)y, ix, iy);
+#pragma unroll
+        for (int ch = 0; ch < C; ++ch) {
+            auto rd_img = [&](int yy, int xx) -> float {
+                return (yy >= 0 && yy < h && xx >= 0 && xx < w)
+                           ? image[((int64_t)yy * w + xx) * C + ch]
+                           : 0.0f;
+            };
+            auto rd_rot = [&](int yr, int xr) -> float {
+                if (!(yr >= 0 && yr < h && xr >= 0 && xr < w)) return 0.0f;
+                return asr_tf_sample(tr, rd_img, xr, yr);
+            };
+            out[ch] = ok ? asr_tf_bilinear(rd_rot, ix, iy) : 0.0f;
+        }
+        float* o = copies + p * C;
+#pragma unroll
+        for (int ch = 0; ch < C; ++ch) o[ch] = out[ch];
+    }
+}
+
+int grid_for(int64_t total) {
+    int64_t g = asr_cdiv(total, kThreads);
+    const int64_t cap = 256 * 16;  // 256 CUs x 16 resident 256-thread blocks, grid-stride beyond
+    return (int)(g < cap ? g : cap);
+}
+
+}  // namespace
+
+extern "C" int asr_warp_affine_f32(const float* src, float* dst, const float* transforms, int n,
+                                   int src_batched, int tf_batched, int h_in, int w_in, int h_out,
+                                   int w_out, int c, asr_stream_t stream) {
+    ASR_REQUIRE(src && dst && transforms, "asr_warp_affine_f32: null pointer");
+    ASR_REQUIRE(n > 0 && h_in > 0 && w_in > 0 && h_out > 0 && w_out > 0 && c > 0,
+                "asr_warp_affine_f32: bad shape n=%d in=%dx%d out=%dx%d c=%d", n, h_in, w_in, h_out,
+                w_out, c);
+    const int64_t total = (int64_t)n * h_out * w_out;
+    hipLaunchKernelGGL(warp_affine_kernel, dim3(grid_for(total)), dim3(kThreads), 0, asr_stream(stream),
+                       src, dst, transforms, n, src_batched, tf_batched, h_in, w_in, h_out, w_out, c);
+    ASR_LAUNCH_CHECK();
+    return ASR_OK;
+}
+
+extern "C" int asr_augment_copies_f32(const float* image, float* copies, const float* rot_tf,
+                                      const float* trans_tf, int n, int h, int w, int c,
+                                      asr_stream_t stream) {
+    ASR_REQUIRE(image && copies && rot_tf && trans_tf, "asr_augment_copies_f32: null pointer");
+    ASR_REQUIRE(n > 0 && h > 0 && w > 0, "asr_augment_copies_f32: bad shape n=%d %dx%d", n, h, w);
+    const int64_t total = (int64_t)n * h * w;
+    const dim3 grid(grid_for(total)), block(kThreads);
+    hipStream_t s = asr_stream(stream);
+    switch (c) {
+        case 1: hipLaunchKernelGGL(augment_copies_kernel<1>, grid, block, 0, s, image, copies, rot_tf, trans_tf, n, h, w); break;
+        case 3: hipLaunchKernelGGL(augment_copies_kernel<3>, grid, block, 0, s, image, copies, rot_tf, trans_tf, n, h, w); break;
+        default:
+            asr_set_error("asr_augment_copies_f32: channels must be 1 or 3, got %d", c);
+            return ASR_ERR_UNSUPPORTED;
+    }
+    ASR_LAUNCH_CHECK();
+    return ASR_OK;
+}

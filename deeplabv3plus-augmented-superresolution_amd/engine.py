@@ -1,0 +1,301 @@
+"""Device execution plan for the DeepLabV3+ (Xception-65, OS16) forward pass.
+
+The reference runs 147 Keras layers as separate library kernels with an HBM round trip each
+(``model.predict``, superresolution_scripts/augmentation_utils.py:76).  Here the graph of
+model.py:64-147 is lowered once into a flat list of C-ABI launches over pre-allocated NHWC
+buffers:
+  * every BatchNorm is folded into the preceding conv's weights + bias (inference affine);
+  * ReLUs, the residual ``Add`` and the stride-2 row gather of shortcut convs live in the
+    epilogue / prologue of the kernel that produces or consumes the tensor;
+  * ``Concatenate`` never copies: producers write straight into channel slices of the concat
+    buffer (``ldy`` = total channels);
+  * activation buffers are recycled by liveness so the working set of the middle flow stays
+    inside the 256 MiB Infinity Cache.
+Replaying the plan is a loop of ctypes calls on the current stream (hipGraph-capturable: the
+launch functions allocate nothing and never synchronise).
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import _lib, ops, weights as W
+
+f32 = torch.float32
+
+
+class _Buf:
+    __slots__ = ("t", "shape", "last_use")
+
+    def __init__(self, t, shape):
+        self.t = t
+        self.shape = shape
+        self.last_use = -1
+
+    @property
+    def ptr(self):
+        return self.t.data_ptr()
+
+
+class _Pool:
+    """Exact-size free list: the net repeats a handful of activation sizes."""
+
+    def __init__(self, device):
+        self.device = device
+        self.free = {}
+        self.total_bytes = 0
+
+    def get(self, numel):
+        lst = self.free.get(numel)
+        if lst:
+            return lst.pop()
+        self.total_bytes += 4 * numel
+        return torch.empty(numel, dtype=f32, device=self.device)
+
+    def put(self, t):
+        self.free.setdefault(t.numel(), []).append(t)
+
+
+def _same_pad(in_size, k_eff, stride):
+    out = -(-in_size // stride)
+    total = max((out - 1) * stride + k_eff - in_size, 0)
+    return out, total // 2
+
+
+class DeeplabEngine:
+    """Folded / packed parameters on the device + per-(batch, H, W) launch plans."""
+
+    def __init__(self, weights: dict, classes=21, device=None):
+        self.device = device or _lib.require_gpu()
+        self.classes = classes
+        self.logits_name = "logits_semantic" if "logits_semantic/kernel" in weights else "custom_logits_semantic"
+        self.p = {}
+        self._plans = {}
+        self._upload(weights)
+
+    # -- parameters -----------------------------------------------------------------------------
+    def _dev(self, a):
+        return torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32)).to(self.device)
+
+    def _put_conv(self, name, bn, eps, pack=True):
+        k, b = (W.fold_conv_bn(self._w, name, bn, eps) if bn else
+                (self._w[name + "/kernel"].reshape(-1, self._w[name + "/kernel"].shape[-1]).astype(np.float32),
+                 self._w.get(name + "/bias")))
+        kd = self._dev(k)
+        self.p[name] = dict(w=ops.pack_pw_weights(kd) if pack else kd, b=self._dev(b) if b is not None else None,
+                            k=k.shape[0], n=k.shape[1])
+
+    def _put_dw(self, name, bn, eps):
+        k, b = W.fold_dw_bn(self._w, name, bn, eps)
+        self.p[name] = dict(w=self._dev(k), b=self._dev(b), c=k.shape[-1])
+
+    def _put_sep(self, prefix, eps):
+        self._put_dw(prefix + "_depthwise", prefix + "_depthwise_BN", eps)
+        self._put_conv(prefix + "_pointwise", prefix + "_pointwise_BN", eps)
+
+    def _upload(self, weights):
+        self._w = weights
+        e3, e5 = W.XCEPTION_BN_EPS, W.HEAD_BN_EPS
+        # entry_flow_conv1_1 keeps its HWIO layout for the direct kernel
+        k, b = W.fold_conv_bn(weights, "entry_flow_conv1_1", "entry_flow_conv1_1_BN", e3)
+        self.p["entry_flow_conv1_1"] = dict(w=self._dev(k), b=self._dev(b), k=k.shape[0], n=k.shape[1])
+        self._put_conv("entry_flow_conv1_2", "entry_flow_conv1_2_BN", e3)
+        for prefix, _cin, _f, skip, _s, _r, _da in W.xception_blocks():
+            for i in range(3):
+                self._put_sep(f"{prefix}_separable_conv{i + 1}", e3)
+            if skip == "conv":
+                self._put_conv(prefix + "_shortcut", prefix + "_shortcut_BN", e3)
+        self._put_conv("image_pooling", "image_pooling_BN", e5)
+        self._put_conv("aspp0", "aspp0_BN", e5)
+        for i in (1, 2, 3):
+            self._put_sep(f"aspp{i}", e3)
+        self._put_conv("concat_projection", "concat_projection_BN", e5)
+        self._put_conv("feature_projection0", "feature_projection0_BN", e5)
+        self._put_sep("decoder_conv0", e5)
+        self._put_sep("decoder_conv1", e5)
+        self._put_conv(self.logits_name, None, None)
+        torch.cuda.synchronize(self.device)
+        del self._w
+
+    # -- plan construction ----------------------------------------------------------------------
+    def _build_plan(self, B, H, Wd):
+        pool = _Pool(self.device)
+        steps = []          # (name, args, kind, flops, bytes)
+        live = []           # buffers to release after a given step index
+
+        def new(shape):
+            n = int(np.prod(shape))
+            return _Buf(pool.get(n), tuple(shape))
+
+        def release(buf):
+            pool.put(buf.t)
+
+        def add(name, args, kind, flops=0, nbytes=0):
+            steps.append((name, tuple(args), kind, float(flops), float(nbytes)))
+
+        def pw(x, name, out=None, out_off=0, ldy=None, relu=False, res=None, sub=1):
+            p = self.p[name]
+            b, h, w, c = x.shape
+            ho, wo = (-(-h // sub), -(-w // sub)) if sub > 1 else (h, w)
+            if out is None:
+                out = new((b, ho, wo, p["n"]))
+                ldy = p["n"]
+            m = b * ho * wo
+            add("asr_pwconv_mfma_f32",
+                (x.ptr, p["w"].data_ptr(), p["b"].data_ptr() if p["b"] is not None else None,
+                 res.ptr if res is not None else None, out.ptr + 4 * out_off, m, p["k"], p["n"], c, ldy,
+                 res.shape[-1] if res is not None else 0, int(relu), sub, h if sub > 1 else 0, w if sub > 1 else 0),
+                "pw", 2.0 * m * p["k"] * p["n"],
+                4.0 * (m * p["k"] + m * p["n"] * (2 if res is not None else 1) + p["k"] * p["n"]))
+            return out
+
+        def dw(x, name, stride, rate, pre_relu, post_relu):
+            p = self.p[name]
+            b, h, w, c = x.shape
+            pad = rate                      # stride 1 'same' and the explicit ZeroPadding2D both give `rate`
+            ho, wo = (h, w) if stride == 1 else ((h + 2 * pad - (2 * rate + 1)) // stride + 1,
+                                                 (w + 2 * pad - (2 * rate + 1)) // stride + 1)
+            out = new((b, ho, wo, c))
+            add("asr_dwconv3x3_nhwc_f32",
+                (x.ptr, p["w"].data_ptr(), p["b"].data_ptr(), out.ptr, b, h, w, c, stride, rate, pad, pad, ho, wo, c, c,
+                 int(pre_relu), int(post_relu), 0),
+                "dw", 18.0 * b * ho * wo * c, 4.0 * (b * h * w * c + b * ho * wo * c + 10 * c))
+            return out
+
+        def sepconv(x, prefix, stride=1, rate=1, depth_act=False, **pw_kw):
+            t = dw(x, prefix + "_depthwise", stride, rate, pre_relu=not depth_act, post_relu=depth_act)
+            y = pw(t, prefix + "_pointwise", relu=depth_act, **pw_kw)
+            release(t)
+            return y
+
+        def block(x, prefix, skip, last_stride, rate, depth_act, return_skip=False, keep_input=False):
+            sc = None
+            if skip == "conv":
+                sc = pw(x, prefix + "_shortcut", sub=last_stride)
+            elif skip == "sum":
+                sc = x
+            r1 = sepconv(x, prefix + "_separable_conv1", 1, rate, depth_act)
+            r2 = sepconv(r1, prefix + "_separable_conv2", 1, rate, depth_act)
+            release(r1)
+            r3 = sepconv(r2, prefix + "_separable_conv3", last_stride, rate, depth_act, res=sc)
+            if not return_skip:
+                release(r2)
+            if skip == "conv":
+                release(sc)
+            if not keep_input:
+                release(x)
+            return (r3, r2) if return_skip else r3
+
+        # ---- entry flow (model.py:149-170) ----
+        x_in = new((B, H, Wd, 3))
+        h1, pt = _same_pad(H, 3, 2)
+        w1, pl = _same_pad(Wd, 3, 2)
+        a1 = new((B, h1, w1, 32))
+        p = self.p["entry_flow_conv1_1"]
+        add("asr_conv3x3_direct_f32", (x_in.ptr, p["w"].data_ptr(), p["b"].data_ptr(), a1.ptr, B, H, Wd, 3, 32, 2, pt, pl,
+                                       h1, w1, 3, 32, 1), "conv", 2.0 * B * h1 * w1 * 27 * 32,
+            4.0 * (B * H * Wd * 3 + B * h1 * w1 * 32))
+        a2 = new((B, h1, w1, 64))
+        p = self.p["entry_flow_conv1_2"]
+        add("asr_conv3x3_mfma_f32", (a1.ptr, p["w"].data_ptr(), p["b"].data_ptr(), a2.ptr, B, h1, w1, 32, 64, 1, 1, 1, h1,
+                                     w1, 32, 64, 1), "conv", 2.0 * B * h1 * w1 * 288 * 64,
+            4.0 * (B * h1 * w1 * 96))
+        release(a1)
+        x = block(a2, "entry_flow_block1", "conv", 2, 1, False)
+        x, skip = block(x, "entry_flow_block2", "conv", 2, 1, False, return_skip=True)
+        x = block(x, "entry_flow_block3", "conv", 2, 1, False)
+        # ---- middle flow (model.py:172-179) ----
+        for i in range(16):
+            x = block(x, f"middle_flow_unit_{i + 1}", "sum", 1, 1, False)
+        # ---- exit flow (model.py:181-190) ----
+        x = block(x, "exit_flow_block1", "conv", 1, 1, False)
+        x = block(x, "exit_flow_block2", None, 1, 2, True)
+        # ---- ASPP (model.py:192-233) ----
+        b, fh, fw, fc = x.shape
+        cat = new((b, fh, fw, 1280))
+        pooled = new((b, 1, 1, fc))
+        add("asr_gap_f32", (x.ptr, pooled.ptr, b, fh * fw, fc, fc), "misc", b * fh * fw * fc, 4.0 * b * fh * fw * fc)
+        pp = pw(pooled, "image_pooling", relu=True)
+        add("asr_resize_bilinear_f32", (pp.ptr, cat.ptr, b, 1, 1, 256, fh, fw, 256, 1280), "misc", 0,
+            4.0 * b * fh * fw * 256)
+        release(pooled)
+        release(pp)
+        pw(x, "aspp0", out=cat, out_off=256, ldy=1280, relu=True)
+        for i, rate in enumerate((6, 12, 18)):
+            t = dw(x, f"aspp{i + 1}_depthwise", 1, rate, pre_relu=False, post_relu=True)
+            pw(t, f"aspp{i + 1}_pointwise", out=cat, out_off=512 + 256 * i, ldy=1280, relu=True)
+            release(t)
+        release(x)
+        x = pw(cat, "concat_projection", relu=True)
+        release(cat)
+        # ---- decoder (model.py:235-259) ----
+        sb, sh, sw, sc_ = skip.shape
+        cat2 = new((sb, sh, sw, 304))
+        add("asr_resize_bilinear_f32", (x.ptr, cat2.ptr, b, fh, fw, 256, sh, sw, 256, 304), "misc", 0,
+            4.0 * sb * sh * sw * 256)
+        release(x)
+        pw(skip, "feature_projection0", out=cat2, out_off=256, ldy=304, relu=True)
+        release(skip)
+        x = sepconv(cat2, "decoder_conv0", 1, 1, True)
+        release(cat2)
+        y = sepconv(x, "decoder_conv1", 1, 1, True)
+        release(x)
+        logits = pw(y, self.logits_name)
+        release(y)
+        plan = dict(steps=steps, x_in=x_in, logits=logits, pool_bytes=pool.total_bytes,
+                    out_shape=(B, sh, sw, self.classes))
+        return plan
+
+    def plan(self, B, H, Wd):
+        key = (B, H, Wd)
+        if key not in self._plans:
+            if H % 16 or Wd % 16:
+                raise ValueError(f"input size must be a multiple of 16 for OS16 (got {H}x{Wd})")
+            self._plans[key] = self._build_plan(B, H, Wd)
+        return self._plans[key]
+
+    # -- execution --------------------------------------------------------------------------------
+    def forward(self, x_dev, profile=None):
+        """x_dev: [B,H,W,3] float32 device tensor -> logits [B,H/4,W/4,classes] (a view of plan
+        memory: consume or clone it before the next forward of the same shape).
+        profile: optional dict kind -> [ms, flops, bytes, launches] filled with HIP-event timings."""
+        B, H, Wd, c = x_dev.shape
+        assert c == 3
+        plan = self.plan(B, H, Wd)
+        xin = plan["x_in"].t
+        xin.copy_(x_dev.reshape(-1))
+        lib = _lib.load()
+        s = _lib.stream_ptr()
+        if profile is None:
+            for name, args, _kind, _fl, _by in plan["steps"]:
+                rc = getattr(lib, name)(*args, s)
+                if rc != 0:
+                    _lib.check(rc, name)
+        else:
+            evs = []
+            for name, args, kind, fl, by in plan["steps"]:
+                e0 = torch.cuda.Event(enable_timing=True)
+                e1 = torch.cuda.Event(enable_timing=True)
+                e0.record()
+                rc = getattr(lib, name)(*args, s)
+                e1.record()
+                if rc != 0:
+                    _lib.check(rc, name)
+                evs.append((kind, e0, e1, fl, by))
+            torch.cuda.synchronize()
+            for kind, e0, e1, fl, by in evs:
+                acc = profile.setdefault(kind, [0.0, 0.0, 0.0, 0])
+                acc[0] += e0.elapsed_time(e1)
+                acc[1] += fl
+                acc[2] += by
+                acc[3] += 1
+        return plan["logits"].t.view(plan["out_shape"])
+
+    def flops_per_copy(self, H, Wd):
+        plan = self.plan(1, H, Wd)
+        out = {}
+        for _n, _a, kind, fl, by in plan["steps"]:
+            acc = out.setdefault(kind, [0.0, 0.0])
+            acc[0] += fl
+            acc[1] += by
+        return out

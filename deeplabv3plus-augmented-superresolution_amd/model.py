@@ -1,0 +1,114 @@
+"""``DeeplabV3Plus`` with the reference's constructor / ``build_model`` / ``predict`` surface
+(model.py:16-147), executing on hand-written gfx950 kernels through ``engine.DeeplabEngine``.
+
+Scope: Xception backbone, OS=16, ``classes`` logits, ``final_upsample`` on or
+off, ``last_activation`` None.  The MobileNetV2 backbone, OS=8, the ``only_*`` decoders and
+``reshape_outputs`` are validated like the reference and then rejected with
+NotImplementedError (not on the hot path).
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import _lib, ops, weights as W
+from .engine import DeeplabEngine
+
+
+class DeeplabV3Plus:
+    def __init__(self, weights='pascal_voc', input_tensor=None, input_shape=(512, 512, 3), classes=21, OS=16,
+                 last_activation=None, load_weights=True, reshape_outputs=False, backbone="xception", alpha=1.,
+                 weights_path=None, synthetic_seed=1234):
+        # same argument checks / messages as model.py:20-30
+        if not (weights in {'pascal_voc', None}):
+            raise ValueError('The `weights` argument should be either '
+                             '`None` (random initialization) or `pascal_voc`'
+                             '(pre-trained on PASCAL VOC)')
+        if not (last_activation in {"softmax", "sigmoid", None}):
+            raise ValueError("The last_activation parameter must be either None, softmax or sigmoid")
+        if not (backbone in {"xception", "mobilenet"}):
+            raise ValueError("Backbone must be either xception or mobilenet")
+        if backbone != "xception":
+            raise NotImplementedError("only the Xception backbone is on the accelerated path")
+        if OS != 16:
+            raise NotImplementedError("only OS=16 is on the accelerated path (model.py:48-52)")
+        if reshape_outputs:
+            raise NotImplementedError("reshape_outputs is not on the accelerated path")
+        if input_tensor is not None:
+            raise NotImplementedError("input_tensor (Keras graph splicing) has no meaning here")
+        self.weights = weights
+        self.input_shape = tuple(input_shape)
+        self.classes = classes
+        self.last_activation = last_activation
+        self.load_weights = load_weights
+        self.backbone = backbone
+        self.alpha = alpha
+        self.OS = OS
+        self.weights_path = weights_path
+        self.synthetic_seed = synthetic_seed
+
+    def build_model(self, only_DCNN_output=False, only_ASPP_output=False, first_upsample_size=(128, 128),
+                    final_upsample=True, final_class_prediction=True):
+        if only_DCNN_output is True and only_ASPP_output is True:
+            raise ValueError("Both only_DCNN_output and only_ASPP_output cannot be True at the same time")
+        if only_DCNN_output or only_ASPP_output or not final_class_prediction:
+            raise NotImplementedError("alternative decoders are not on the accelerated path")
+        if self.load_weights and self.weights_path is not None:
+            params = W.load_weights(self.weights_path)          # local file only (never the URL of model.py:9)
+        else:
+            # The pretrained .h5 is a network download (model.py:134-143): unavailable offline.
+            params = W.make_synthetic_weights(self.synthetic_seed, self.classes)
+        return DeeplabModel(params, self.input_shape, self.classes, final_upsample, self.last_activation)
+
+
+class DeeplabModel:
+    """What ``build_model`` returns: only ``predict`` (and ``predict_device``) are used by callers
+    (augmentation_utils.py:76)."""
+
+    def __init__(self, params, input_shape, classes, final_upsample, last_activation):
+        self.input_shape = tuple(input_shape)
+        self.classes = classes
+        self.final_upsample = final_upsample
+        self.last_activation = last_activation
+        self.name = "DLV3Plus-xception-OS16"
+        self.engine = DeeplabEngine(params, classes)
+        self.device = self.engine.device
+
+    def predict_device(self, x, batch_size=16, profile=None):
+        """x: [N,H,W,3] float32 (host array or device tensor) -> device tensor [N,h,w,classes]."""
+        if not isinstance(x, torch.Tensor):
+            x = torch.as_tensor(np.ascontiguousarray(x, dtype=np.float32))
+        n, h, w, c = x.shape
+        if c != 3:
+            raise ValueError(f"expected [N,H,W,3], got {tuple(x.shape)}")
+        outs = []
+        for i in range(0, n, batch_size):
+            xb = x[i:i + batch_size].to(self.device, non_blocking=True).contiguous()
+            logits = self.engine.forward(xb, profile=profile)
+            if self.final_upsample:
+                logits = self._upsample(logits, (h, w))
+            else:
+                logits = logits.clone()
+            outs.append(logits)
+        out = outs[0] if len(outs) == 1 else torch.cat(outs, dim=0)
+        if self.last_activation == "softmax":
+            out = torch.softmax(out, dim=-1)     # device-side torch op (not on the measured path)
+        elif self.last_activation == "sigmoid":
+            out = torch.sigmoid(out)
+        return out
+
+    def _upsample(self, logits, hw):
+        """Resizing(H, W, bilinear) of the logits (model.py:108-111); channels padded to a multiple
+        of 4 for the 16-byte lanes of the kernel."""
+        b, h, w, c = logits.shape
+        cp = (c + 3) // 4 * 4
+        padded = torch.zeros((b, h, w, cp), dtype=torch.float32, device=logits.device)
+        padded[..., :c] = logits
+        up = ops.resize_bilinear(padded, hw)
+        return up[..., :c].contiguous()
+
+    def predict(self, x, batch_size=16, verbose=0):
+        """Keras ``Model.predict`` counterpart: host ndarray in, host ndarray out."""
+        return self.predict_device(x, batch_size=batch_size).cpu().numpy()
+
+    __call__ = predict_device

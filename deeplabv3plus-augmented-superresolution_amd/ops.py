@@ -1,0 +1,310 @@
+"""Thin tensor-level wrappers over the C ABI (include/asr_hip.h).
+
+Every function takes contiguous float32 ROCm tensors, checks shapes on the host (a kernel that
+indexes out of bounds can take the whole node down), launches on torch's current stream and
+returns device tensors.  Nothing here computes on the CPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import AsrError, call, ptr, stream_ptr
+
+f32 = torch.float32
+
+
+def _dev(t):
+    return t.device
+
+
+def to_device(a, dtype=f32, device=None):
+    device = device or _lib.require_gpu()
+    if isinstance(a, torch.Tensor):
+        return a.to(device=device, dtype=dtype).contiguous()
+    return torch.as_tensor(np.ascontiguousarray(a), dtype=dtype).to(device)
+
+
+# ---------------------------------------------------------------------------------------------
+# warps
+# ---------------------------------------------------------------------------------------------
+def warp_affine(src, transforms, out_hw=None, n=None):
+    """src [N,H,W,C] or [H,W,C] (shared), transforms [N,8] or [8] (shared) -> [N,Ho,Wo,C]."""
+    src_b = src.dim() == 4
+    tf_b = transforms.dim() == 2
+    if src_b:
+        n_src, h, w, c = src.shape
+    else:
+        h, w, c = src.shape
+        n_src = None
+    n_tf = transforms.shape[0] if tf_b else None
+    n = n or n_src or n_tf or 1
+    if (n_src is not None and n_src != n) or (n_tf is not None and n_tf != n):
+        raise AsrError(f"warp_affine: batch mismatch src={n_src} transforms={n_tf} n={n}")
+    if transforms.shape[-1] != 8:
+        raise AsrError("warp_affine: transforms must have 8 coefficients")
+    ho, wo = out_hw or (h, w)
+    dst = torch.empty((n, ho, wo, c), dtype=f32, device=src.device)
+    call("asr_warp_affine_f32", ptr(src), ptr(dst), ptr(transforms), n, int(src_b), int(tf_b), h, w, ho, wo, c,
+         stream_ptr())
+    return dst
+
+
+def augment_copies(image, rot_tf, trans_tf):
+    """image [H,W,C] -> [N,H,W,C] = translate(rotate(tile(image)))."""
+    h, w, c = image.shape
+    n = rot_tf.shape[0]
+    if rot_tf.shape != (n, 8) or trans_tf.shape != (n, 8):
+        raise AsrError("augment_copies: transforms must be [N,8]")
+    out = torch.empty((n, h, w, c), dtype=f32, device=image.device)
+    call("asr_augment_copies_f32", ptr(image), ptr(out), ptr(rot_tf), ptr(trans_tf), n, h, w, c, stream_ptr())
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
+# SR
+# ---------------------------------------------------------------------------------------------
+def _sr_dims(x, y):
+    if x.dim() != 3 or y.dim() != 4 or x.shape[0] != y.shape[0]:
+        raise AsrError(f"SR tensors: x [B,H,W] and y [B,N,h,w] expected, got {tuple(x.shape)} {tuple(y.shape)}")
+    b, H, W = x.shape
+    _, n, h, w = y.shape
+    return b, n, H, W, h, w
+
+
+def _check_tf(t, b, n, name):
+    if tuple(t.shape) != (b, n, 8):
+        raise AsrError(f"{name} must be [{b},{n},8], got {tuple(t.shape)}")
+
+
+def sr_init_target(y, out_hw):
+    b, n, h, w = y.shape
+    x = torch.empty((b, out_hw[0], out_hw[1]), dtype=f32, device=y.device)
+    call("asr_sr_init_target_f32", ptr(y), ptr(x), b, n, out_hw[0], out_hw[1], h, w, stream_ptr())
+    return x
+
+
+def sr_forward_residual(x, y, rot_tf, trans_tf):
+    b, n, H, W, h, w = _sr_dims(x, y)
+    _check_tf(rot_tf, b, n, "rot_tf")
+    _check_tf(trans_tf, b, n, "trans_tf")
+    resid = torch.empty_like(y)
+    call("asr_sr_forward_residual_f32", ptr(x), ptr(y), ptr(rot_tf), ptr(trans_tf), ptr(resid), b, n, H, W, h, w,
+         stream_ptr())
+    return resid
+
+
+def sr_backward_adam(x, resid, inv_rot_tf, inv_trans_tf, lambdas, adam=None, want_grad=False):
+    """One step.  lambdas = (df, tv, l2, l1).  adam = dict(m, v, vhat, alphas[B], one_minus_beta1,
+    one_minus_beta2, epsilon, amsgrad) or None for gradient only.  Returns (x_new | None, grad | None)."""
+    b, n, H, W, h, w = _sr_dims(x, resid)
+    _check_tf(inv_rot_tf, b, n, "inv_rot_tf")
+    _check_tf(inv_trans_tf, b, n, "inv_trans_tf")
+    grad = torch.empty_like(x) if (want_grad or adam is None) else None
+    x_new = torch.empty_like(x) if adam is not None else None
+    if adam is not None:
+        for k in ("m", "v"):
+            if adam[k].shape != x.shape:
+                raise AsrError(f"adam['{k}'] shape mismatch")
+        if adam["alphas"].numel() != b:
+            raise AsrError("adam['alphas'] must hold one value per image")
+    a = adam or {}
+    call("asr_sr_backward_adam_f32", ptr(x), ptr(x_new, allow_none=True), ptr(resid), ptr(inv_rot_tf),
+         ptr(inv_trans_tf), ptr(a.get("m"), allow_none=True), ptr(a.get("v"), allow_none=True),
+         ptr(a.get("vhat"), allow_none=True), ptr(a.get("alphas"), allow_none=True), ptr(grad, allow_none=True),
+         b, n, H, W, h, w, float(lambdas[0]), float(lambdas[1]), float(lambdas[2]), float(lambdas[3]),
+         float(a.get("one_minus_beta1", 0.0)), float(a.get("one_minus_beta2", 0.0)), float(a.get("epsilon", 0.0)),
+         int(bool(a.get("amsgrad", False))), stream_ptr())
+    return x_new, grad
+
+
+def sr_loss_terms(x, resid):
+    b, n, H, W, h, w = _sr_dims(x, resid)
+    terms = torch.empty((b, 4), dtype=torch.float64, device=x.device)
+    call("asr_sr_loss_terms_f64", ptr(x), ptr(resid), ptr(terms, torch.float64), b, n, H, W, h, w, stream_ptr())
+    return terms
+
+
+def sr_solve(x, y, rot_tf, trans_tf, inv_rot_tf, inv_trans_tf, alphas, lambdas, one_minus_beta1, one_minus_beta2,
+             epsilon, amsgrad, want_loss=True):
+    """Runs alphas.shape[0] iterations in place on x.  alphas [num_iter, B] (device)."""
+    b, n, H, W, h, w = _sr_dims(x, y)
+    for t, name in ((rot_tf, "rot_tf"), (trans_tf, "trans_tf"), (inv_rot_tf, "inv_rot_tf"), (inv_trans_tf, "inv_trans_tf")):
+        _check_tf(t, b, n, name)
+    if alphas.dim() != 2 or alphas.shape[1] != b:
+        raise AsrError(f"alphas must be [num_iter,{b}]")
+    num_iter = alphas.shape[0]
+    lib = _lib.load()
+    ws_bytes = lib.asr_sr_solve_workspace_bytes(b, n, H, W, h, w)
+    ws = torch.empty((ws_bytes + 3) // 4, dtype=f32, device=x.device)
+    m = torch.zeros_like(x)
+    v = torch.zeros_like(x)
+    vhat = torch.zeros_like(x)
+    terms = torch.zeros((b, 4), dtype=torch.float64, device=x.device) if want_loss else None
+    call("asr_sr_solve_f32", ptr(x), ptr(y), ptr(rot_tf), ptr(trans_tf), ptr(inv_rot_tf), ptr(inv_trans_tf), ptr(m),
+         ptr(v), ptr(vhat), ptr(alphas), num_iter, ptr(terms, torch.float64, allow_none=True), ptr(ws),
+         C.c_size_t(ws_bytes), b, n, H, W, h, w, float(lambdas[0]), float(lambdas[1]), float(lambdas[2]),
+         float(lambdas[3]), float(one_minus_beta1), float(one_minus_beta2), float(epsilon), int(bool(amsgrad)),
+         stream_ptr())
+    return x, terms
+
+
+def realign(y, trans_tf, rot_tf, out_hw, mode):
+    if y.dim() != 4:
+        raise AsrError("realign: y must be [B,N,h,w]")
+    b, n, h, w = y.shape
+    _check_tf(trans_tf, b, n, "trans_tf")
+    _check_tf(rot_tf, b, n, "rot_tf")
+    out = torch.empty((b, out_hw[0], out_hw[1]), dtype=f32, device=y.device)
+    fn = {"max": "asr_realign_max_f32", "mean": "asr_realign_mean_f32"}[mode]
+    call(fn, ptr(y), ptr(out), ptr(trans_tf), ptr(rot_tf), b, n, out_hw[0], out_hw[1], h, w, stream_ptr())
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
+# OPM / threshold / IoU
+# ---------------------------------------------------------------------------------------------
+def minmax(x, segments=1):
+    per = x.numel() // segments
+    if per * segments != x.numel() or per == 0:
+        raise AsrError("minmax: tensor does not split into equal non-empty segments")
+    out = torch.empty((segments, 2), dtype=f32, device=x.device)
+    call("asr_minmax_f32", ptr(x), ptr(out), per, segments, stream_ptr())
+    return out
+
+
+def argmax(logits):
+    classes = logits.shape[-1]
+    pixels = logits.numel() // classes
+    out = torch.empty(logits.shape[:-1], dtype=torch.int32, device=logits.device)
+    call("asr_argmax_i32", ptr(logits), ptr(out, torch.int32), pixels, classes, stream_ptr())
+    return out
+
+
+def opm_argmax(logits, class_id):
+    classes = logits.shape[-1]
+    pixels = logits.numel() // classes
+    out = torch.empty(logits.shape[:-1], dtype=f32, device=logits.device)
+    call("asr_opm_argmax_f32", ptr(logits), ptr(out), pixels, classes, class_id, stream_ptr())
+    return out
+
+
+def opm_slice_max(logits, class_id):
+    classes = logits.shape[-1]
+    pixels = logits.numel() // classes
+    cls = torch.empty(logits.shape[:-1], dtype=f32, device=logits.device)
+    mx = torch.empty_like(cls)
+    call("asr_opm_slice_max_f32", ptr(logits), ptr(cls), ptr(mx), pixels, classes, class_id, stream_ptr())
+    return cls, mx
+
+
+def opm_slice(logits, class_id, new_min=0.0, new_max=1.0):
+    """logits [N,h,w,C]: per-copy global min/max normalisation of the class slice."""
+    n = logits.shape[0]
+    classes = logits.shape[-1]
+    per_copy = logits.numel() // (n * classes)
+    out = torch.empty(logits.shape[:-1], dtype=f32, device=logits.device)
+    ws = torch.empty((n, 2), dtype=f32, device=logits.device)
+    call("asr_opm_slice_f32", ptr(logits), ptr(out), ptr(ws), n, per_copy, classes, class_id, float(new_min),
+         float(new_max), stream_ptr())
+    return out
+
+
+def threshold(image, th_value, th_factor=0.15, th_mask=None, segments=1):
+    per = image.numel() // segments
+    out = torch.empty(image.shape, dtype=torch.int32, device=image.device)
+    ws = torch.empty((segments, 2), dtype=f32, device=image.device)
+    if th_mask is not None and th_mask.shape != image.shape:
+        raise AsrError("threshold: th_mask shape mismatch")
+    call("asr_threshold_f32", ptr(image), ptr(th_mask, allow_none=True), ptr(ws), ptr(out, torch.int32), per, segments,
+         float(np.float32(th_factor)), int(th_value), stream_ptr())
+    return out
+
+
+def iou_counts(truth, pred, class_id, include_bg=False, segments=1):
+    if truth.numel() != pred.numel():
+        raise AsrError("iou_counts: size mismatch")
+    per = truth.numel() // segments
+    counts = torch.empty((segments, 4), dtype=torch.int64, device=truth.device)
+    call("asr_iou_counts_i32", ptr(truth, torch.int32), ptr(pred, torch.int32), ptr(counts, torch.int64), per, segments,
+         int(class_id), int(bool(include_bg)), stream_ptr())
+    return counts
+
+
+# ---------------------------------------------------------------------------------------------
+# model layers
+# ---------------------------------------------------------------------------------------------
+def pack_pw_weights(w_kn):
+    k, n = w_kn.shape
+    lib = _lib.load()
+    out = torch.empty(lib.asr_pwconv_packed_floats(k, n), dtype=f32, device=w_kn.device)
+    call("asr_pwconv_pack_weights_f32", ptr(w_kn), ptr(out), k, n, stream_ptr())
+    return out
+
+
+def pwconv(x, w_packed, bias, k, n, out=None, residual=None, relu=False, ldx=None, ldy=None, ldres=None, m=None,
+           sub_stride=1, h_in=0, w_in=0):
+    """Rows of x ([..., ldx] with the first k columns used) times packed W [k,n]."""
+    ldx = ldx or x.shape[-1]
+    m = m if m is not None else x.numel() // ldx
+    if out is None:
+        out = torch.empty((m, n), dtype=f32, device=x.device)
+        ldy = n
+    ldy = ldy or out.shape[-1]
+    ldres = ldres or (residual.shape[-1] if residual is not None else 0)
+    call("asr_pwconv_mfma_f32", ptr(x), ptr(w_packed), ptr(bias, allow_none=True), ptr(residual, allow_none=True),
+         ptr(out), m, k, n, ldx, ldy, ldres, int(relu), sub_stride, h_in, w_in, stream_ptr())
+    return out
+
+
+def conv3x3_mfma(x, w_packed, bias, cout, stride=1, pad=1, dil=1, relu=False):
+    b, h, w, cin = x.shape
+    ho = (h + 2 * pad - (2 * dil + 1)) // stride + 1
+    wo = (w + 2 * pad - (2 * dil + 1)) // stride + 1
+    y = torch.empty((b, ho, wo, cout), dtype=f32, device=x.device)
+    call("asr_conv3x3_mfma_f32", ptr(x), ptr(w_packed), ptr(bias, allow_none=True), ptr(y), b, h, w, cin, cout, stride,
+         pad, dil, ho, wo, cin, cout, int(relu), stream_ptr())
+    return y
+
+
+def conv3x3_direct(x, w_hwio, bias, stride, pad_top, pad_left, out_hw, relu=False):
+    b, h, w, cin = x.shape
+    cout = w_hwio.shape[-1]
+    y = torch.empty((b, out_hw[0], out_hw[1], cout), dtype=f32, device=x.device)
+    call("asr_conv3x3_direct_f32", ptr(x), ptr(w_hwio), ptr(bias), ptr(y), b, h, w, cin, cout, stride, pad_top,
+         pad_left, out_hw[0], out_hw[1], cin, cout, int(relu), stream_ptr())
+    return y
+
+
+def dwconv3x3(x, w_33c, bias, stride=1, rate=1, pad_top=None, pad_left=None, out_hw=None, pre_relu=False,
+              post_relu=False, force_direct=False, out=None, ldy=None):
+    b, h, w, c = x.shape
+    if pad_top is None:
+        pad_top = pad_left = rate            # stride-1 'same'
+    if out_hw is None:
+        out_hw = (h, w)
+    if out is None:
+        out = torch.empty((b, out_hw[0], out_hw[1], c), dtype=f32, device=x.device)
+    ldy = ldy or out.shape[-1]
+    call("asr_dwconv3x3_nhwc_f32", ptr(x), ptr(w_33c), ptr(bias), ptr(out), b, h, w, c, stride, rate, pad_top, pad_left,
+         out_hw[0], out_hw[1], c, ldy, int(pre_relu), int(post_relu), int(force_direct), stream_ptr())
+    return out
+
+
+def gap(x):
+    b, h, w, c = x.shape
+    y = torch.empty((b, c), dtype=f32, device=x.device)
+    call("asr_gap_f32", ptr(x), ptr(y), b, h * w, c, c, stream_ptr())
+    return y
+
+
+def resize_bilinear(x, out_hw, out=None, ldy=None):
+    b, h, w, c = x.shape
+    if out is None:
+        out = torch.empty((b, out_hw[0], out_hw[1], c), dtype=f32, device=x.device)
+    ldy = ldy or out.shape[-1]
+    call("asr_resize_bilinear_f32", ptr(x), ptr(out), b, h, w, c, out_hw[0], out_hw[1], c, ldy, stream_ptr())
+    return out

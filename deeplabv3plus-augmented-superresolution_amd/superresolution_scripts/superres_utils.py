@@ -1,0 +1,152 @@
+"""SR glue with the reference's surface (superresolution_scripts/superres_utils.py):
+``min_max_normalization`` (:56-62), ``threshold_image`` (:118-139), ``load_SR_data`` (:154-210),
+``compute_SR`` (:213-273), plus ``list_precomputed_data_paths`` / ``check_validity`` for the
+two-stage workflow.  The interchange file is an ``.npz`` with the reference's HDF5 dataset and
+attribute names (h5py is not available in this image).
+"""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+import torch
+
+from .. import _lib, ops
+
+DATA_EXT = ".npz"
+
+
+def min_max_normalization(image, new_min=0.0, new_max=255.0, global_min=None, global_max=None):
+    """Host arrays: numpy float32 arithmetic in the reference's order.  Device tensors stay on the device."""
+    if isinstance(image, torch.Tensor) and image.is_cuda:
+        mm = ops.minmax(image.contiguous())[0]
+        mn = mm[0] if global_min is None else torch.as_tensor(global_min, dtype=torch.float32, device=image.device)
+        mx = mm[1] if global_max is None else torch.as_tensor(global_max, dtype=torch.float32, device=image.device)
+        den = mx - mn
+        den = torch.where(den != 0, den, torch.ones_like(den))
+        return new_min + ((image - mn) * (new_max - new_min)) / den
+    image = np.asarray(image)
+    mn = image.min() if global_min is None else global_min
+    mx = image.max() if global_max is None else global_max
+    num = (image - mn) * (new_max - new_min)
+    den = (mx - mn) if (mx - mn) != 0 else 1.0
+    return new_min + (num / den)
+
+
+def threshold_image(image, th_value, th_factor=.15, th_mask=None):
+    """{0, th_value} int32 mask: image >= th_mask, or image > th_factor * max(image).  Runs on the
+    device (asr_threshold_f32); returns a host array for host input, a device tensor otherwise."""
+    was_tensor = isinstance(image, torch.Tensor)
+    dev = _lib.require_gpu()
+    img = image if was_tensor else torch.as_tensor(np.asarray(image, dtype=np.float32))
+    img = img.to(device=dev, dtype=torch.float32).contiguous()
+    tm = None
+    if th_mask is not None:
+        tm = th_mask if isinstance(th_mask, torch.Tensor) else torch.as_tensor(np.asarray(th_mask, dtype=np.float32))
+        tm = tm.to(device=dev, dtype=torch.float32).contiguous()
+    out = ops.threshold(img, th_value, th_factor=th_factor, th_mask=tm)
+    return out if was_tensor else out.cpu().numpy()
+
+
+# ---- interchange file (augmentation_utils.py:117-136 writer, superres_utils.py:154-210 reader) -------
+def save_SR_data(path_without_ext, class_masks, max_masks, angles, shifts, filename, mode, angle_max, shift_max):
+    os.makedirs(os.path.dirname(path_without_ext) or ".", exist_ok=True)
+    data = dict(class_masks=np.asarray(class_masks, dtype=np.float32), angles=np.asarray(angles, dtype=np.float32),
+                shifts=np.asarray(shifts, dtype=np.float32), filename=np.array(filename), mode=np.array(mode),
+                angle_max=np.array(angle_max), shift_max=np.array(shift_max))
+    if max_masks is not None and len(max_masks):
+        data["max_masks"] = np.asarray(max_masks, dtype=np.float32)
+    np.savez(path_without_ext + DATA_EXT, **data)
+    return path_without_ext + DATA_EXT
+
+
+def list_precomputed_data_paths(root_dir, sort=False):
+    paths = []
+    for path, _subdirs, files in os.walk(root_dir):
+        for filename in files:
+            if filename.endswith(DATA_EXT):
+                paths.append(os.path.join(path, filename))
+    if sort:
+        paths = sorted(paths, key=lambda p: int(os.path.basename(p).split('.')[0]))
+    return paths
+
+
+def check_validity(file, num_aug=100):
+    """Every array dataset has at least num_aug entries (superres_utils.py:108-115)."""
+    for key in ("class_masks", "max_masks", "angles", "shifts"):
+        if key in file and file[key].shape[0] < num_aug:
+            return False
+    return True
+
+
+def load_SR_data(filepath, num_aug=100, global_normalize=True):
+    """Returns (class_masks [N,h,w,1], max_masks | None, angles, shifts, filename) as host arrays;
+    argmax / slice_max masks are min-max normalised to [0,1] (superres_utils.py:183-206)."""
+    with np.load(filepath, allow_pickle=False) as file:
+        if not check_validity(file, num_aug=num_aug):
+            raise Exception(f"File: {filepath} is invalid")
+        filename = str(file["filename"])
+        mode = str(file["mode"])
+        angles = file["angles"][:num_aug]
+        shifts = file["shifts"][:num_aug]
+        class_masks = file["class_masks"][:num_aug].astype(np.float32)
+        max_masks = file["max_masks"][:num_aug].astype(np.float32) if mode == "slice_max" else None
+
+    def normalise(stack):
+        if global_normalize:
+            gmin, gmax = stack.min(), stack.max()
+            return np.stack([min_max_normalization(im, 0.0, 1.0, gmin, gmax) for im in stack]).astype(np.float32)
+        return np.stack([min_max_normalization(im, 0.0, 1.0) for im in stack]).astype(np.float32)
+
+    if mode != "slice":
+        class_masks = normalise(class_masks)
+    if max_masks is not None:
+        max_masks = normalise(max_masks)
+    return class_masks, max_masks, angles, shifts, filename
+
+
+def _save_png(path, image, scale=True):
+    from PIL import Image
+    a = np.asarray(image, dtype=np.float32)
+    a = a[..., 0] if a.ndim == 3 else a
+    if scale:                                   # tf.keras.utils.save_img(scale=True)
+        a = a - a.min()
+        mx = a.max()
+        if mx != 0:
+            a = a / mx
+        a = a * 255.0
+    Image.fromarray(a.astype(np.uint8)).save(path)
+
+
+def compute_SR(superresolution_obj, class_masks, angles, shifts, filename, dest_folder,
+               SR_type="aug", max_masks=[], save_intermediate_output=False, save_final_output=False, class_id=8,
+               th_factor=0.15):
+    """Dispatch aug / mean / max SR, then threshold to a {0, class_id} mask [H,W,1] (host int32)."""
+    out_folder = os.path.join(dest_folder, f"{SR_type}_SR")
+    if not os.path.exists(out_folder):
+        os.makedirs(out_folder)
+    if SR_type == "aug":
+        SR_function = superresolution_obj.augmented_superresolution
+    elif SR_type == "mean":
+        SR_function = superresolution_obj.mean_superresolution
+    elif SR_type == "max":
+        SR_function = superresolution_obj.max_superresolution
+    else:
+        raise ValueError("SR_type must be either 'aug', 'mean' or 'max'")
+
+    target_image_class, _ = SR_function(class_masks, angles, shifts)
+    target_image_max = None
+    # the max mask is super-resolved only when it was produced, i.e. in slice_max OPM
+    if max_masks is not None and len(max_masks) == len(class_masks):
+        target_image_max, _ = SR_function(max_masks, angles, shifts)
+        th_mask = threshold_image(target_image_class, class_id, th_mask=target_image_max)
+    else:
+        th_mask = threshold_image(target_image_class, class_id, th_factor=th_factor)
+
+    if save_intermediate_output:
+        _save_png(f"{out_folder}/{filename}_class.png", target_image_class)
+        if target_image_max is not None:
+            _save_png(f"{out_folder}/{filename}_max.png", target_image_max)
+    if save_final_output:
+        _save_png(f"{out_folder}/{filename}_{SR_type}_SR.png", th_mask)
+    return th_mask

@@ -1,0 +1,156 @@
+"""``Superresolution`` with the reference's surface (superresolution_scripts/superresolution.py:26-161):
+``loss_function``, ``augmented_superresolution``, ``max_superresolution``, ``mean_superresolution``
+-- plus batched variants that solve many images in one sequence of launches.  All arithmetic
+runs in the fused HIP kernels of csrc/sr.hip; this class only prepares float32 parameters.
+
+``use_BTV`` and ``copy_dropout`` (default off in every shipped configuration) are rejected:
+SURVEY 8f item 3.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from .. import _lib, ops, transforms as T
+from .optimizer import Optimizer
+
+
+def _stack_copies(copies, device):
+    """list of [h,w,1] / [h,w] arrays, stacked ndarray or tensor -> device tensor [N,h,w]."""
+    if isinstance(copies, torch.Tensor):
+        t = copies.to(device=device, dtype=torch.float32)
+    else:
+        if isinstance(copies, (list, tuple)):
+            if len(copies) and isinstance(copies[0], torch.Tensor):
+                t = torch.stack([c.to(device=device, dtype=torch.float32) for c in copies])
+            else:
+                t = torch.as_tensor(np.stack([np.asarray(c, dtype=np.float32) for c in copies])).to(device)
+        else:
+            t = torch.as_tensor(np.asarray(copies, dtype=np.float32)).to(device)
+    if t.dim() == 4 and t.shape[-1] == 1:
+        t = t[..., 0]
+    if t.dim() != 3:
+        raise ValueError(f"augmented copies must be [N,h,w(,1)], got {tuple(t.shape)}")
+    return t.contiguous()
+
+
+class Superresolution:
+    def __init__(self, lambda_df, lambda_tv, lambda_L2, lambda_L1, num_iter=200, num_aug=100,
+                 optimizer: Optimizer = None, feature_size=(64, 64), output_size=(512, 512), use_BTV=False,
+                 verbose=False, copy_dropout=0.0):
+        if use_BTV:
+            raise NotImplementedError("bilateral TV (superresolution.py:8-23) is not on the accelerated path")
+        if copy_dropout:
+            raise NotImplementedError("copy_dropout (superresolution.py:47-53) is not on the accelerated path")
+        self.lambda_df = lambda_df
+        self.lambda_tv = lambda_tv
+        self.lambda_L2 = lambda_L2
+        self.lambda_L1 = lambda_L1
+        self.num_iter = num_iter
+        self.num_aug = num_aug
+        self.optimizer = optimizer
+        self.feature_size = tuple(feature_size)
+        self.output_size = tuple(output_size)
+        self.use_BTV = use_BTV
+        self.verbose = verbose
+        self.copy_dropout = copy_dropout
+
+    # -- parameter preparation ----------------------------------------------------------------
+    @property
+    def _lambdas(self):
+        return (self.lambda_df, self.lambda_tv, self.lambda_L2, self.lambda_L1)
+
+    def _transforms(self, angles, shifts, device, inverse=False, negate=False):
+        """angles [B,N], shifts [B,N,2] -> device [B,N,8] rotation and translation transforms."""
+        H, Wd = self.output_size
+        angles = np.asarray(angles, dtype=np.float32)
+        shifts = np.asarray(shifts, dtype=np.float32)
+        if negate:
+            angles, shifts = -angles, -shifts
+        b, n = angles.shape
+        rot = T.rotation_transforms(angles.reshape(-1), H, Wd)
+        tr = T.translation_transforms(shifts.reshape(-1, 2))
+        if inverse:
+            rot, tr = T.inverse_transforms(rot), T.inverse_transforms(tr)
+        return ops.to_device(rot.reshape(b, n, 8), device=device), ops.to_device(tr.reshape(b, n, 8), device=device)
+
+    @staticmethod
+    def _batchify(angles, shifts):
+        a = np.asarray(angles, dtype=np.float32)
+        s = np.asarray(shifts, dtype=np.float32)
+        return (a[None], s[None]) if a.ndim == 1 else (a, s)
+
+    # -- superresolution.py:44-100 ------------------------------------------------------------------
+    def loss_function(self, target_image, augmented_samples, angles, shifts, n_drop=0):
+        if n_drop != 0:
+            raise NotImplementedError("copy dropout is not on the accelerated path")
+        dev = _lib.require_gpu()
+        y = _stack_copies(augmented_samples, dev)[None]
+        x = torch.as_tensor(np.asarray(target_image.cpu() if isinstance(target_image, torch.Tensor) else target_image,
+                                       dtype=np.float32)).to(dev).reshape(1, *self.output_size).contiguous()
+        a, s = self._batchify(angles, shifts)
+        rot, tr = self._transforms(a, s, dev)
+        resid = ops.sr_forward_residual(x, y, rot, tr)
+        return self._loss_from_terms(ops.sr_loss_terms(x, resid).cpu().numpy()[0])
+
+    def _loss_from_terms(self, t):
+        f = np.float32
+        loss = f(self.lambda_df) * f(t[0]) + f(self.lambda_tv) * f(t[1])
+        loss = loss + f(self.lambda_L2) * f(t[2])
+        if self.lambda_L1 > 0.0:
+            loss = loss + f(self.lambda_L1) * f(t[3])
+        return float(loss)
+
+    # -- superresolution.py:102-137 -------------------------------------------------------------------
+    def augmented_superresolution_batch(self, copies, angles, shifts):
+        """copies [B,N,h,w] device tensor, angles [B,N], shifts [B,N,2] -> (device [B,H,W], [B] losses).
+        The global Adam step counter advances image by image (reference order), the device then
+        iterates all images together."""
+        if self.optimizer is None:
+            raise Exception("You must provide an instance of the Optimizer class to compute the augmented SR")
+        dev = copies.device
+        b, n, h, w = copies.shape
+        if (h, w) != self.feature_size:
+            raise ValueError(f"copies are {h}x{w} but feature_size is {self.feature_size}")
+        rot, tr = self._transforms(angles, shifts, dev)
+        irot, itr = self._transforms(angles, shifts, dev, inverse=True)
+        alphas = np.stack([self.optimizer.schedule_alphas(self.num_iter) for _ in range(b)], axis=1)  # [iter, B]
+        adam = self.optimizer.optimizer
+        x = ops.sr_init_target(copies, self.output_size)
+        if self.num_iter == 0:
+            return x, [None] * b
+        one = np.float32(1.0)
+        x, terms = ops.sr_solve(x, copies, rot, tr, irot, itr, ops.to_device(alphas, device=dev), self._lambdas,
+                                one - adam.beta_1, one - adam.beta_2, adam.epsilon, adam.amsgrad, want_loss=True)
+        return x, terms
+
+    def augmented_superresolution(self, augmented_copies, angles, shifts):
+        if self.optimizer is None:
+            raise Exception(
+                "You must provide an instance of the Optimizer class to compute the augmented SR")
+        dev = _lib.require_gpu()
+        y = _stack_copies(augmented_copies, dev)[None]
+        a, s = self._batchify(angles, shifts)
+        x, terms = self.augmented_superresolution_batch(y, a, s)
+        loss = self._loss_from_terms(terms.cpu().numpy()[0]) if isinstance(terms, torch.Tensor) else None
+        if self.verbose and loss is not None:
+            print(f"{self.num_iter}/{self.num_iter} -- loss = {loss}")
+        return x[0].cpu().numpy()[..., None], loss
+
+    # -- superresolution.py:139-161 ---------------------------------------------------------------------
+    def realign_batch(self, copies, angles, shifts, mode):
+        """copies [B,N,h,w] device -> device [B,H,W]; translate(-shift) then rotate(-angle), max / mean."""
+        rot, tr = self._transforms(angles, shifts, copies.device, negate=True)
+        return ops.realign(copies, tr, rot, self.output_size, mode)
+
+    def _realign_single(self, augmented_copies, angles, shifts, mode):
+        dev = _lib.require_gpu()
+        y = _stack_copies(augmented_copies, dev)[None]
+        a, s = self._batchify(angles, shifts)
+        return self.realign_batch(y, a, s, mode)[0].cpu().numpy()[..., None], None
+
+    def max_superresolution(self, augmented_copies, angles, shifts):
+        return self._realign_single(augmented_copies, angles, shifts, "max")
+
+    def mean_superresolution(self, augmented_copies, angles, shifts):
+        return self._realign_single(augmented_copies, angles, shifts, "mean")

@@ -1,0 +1,170 @@
+"""DeepLabV3+ (Xception-65, OS16) parameter inventory, synthetic initialisation and BN folding.
+
+Names, shapes and BatchNorm epsilons follow the reference's Keras graph (model.py:149-306,
+381-424, 463-541) so that a weight file exported from the reference model
+(``{layer_name}/{variable}`` -> array, Keras layouts: Conv2D HWIO, DepthwiseConv2D [3,3,C,1])
+loads by name, like ``load_weights(by_name=True)`` (model.py:145).  The pretrained bonlime .h5
+(model.py:9) is a network download and is not available offline; ``make_synthetic_weights``
+produces seeded random parameters of the same architecture instead.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+XCEPTION_BN_EPS = 1e-3   # Keras default: every Xception-flow BN and aspp1-3 (model.py:214-221)
+HEAD_BN_EPS = 1e-5       # image_pooling, aspp0, concat_projection, feature_projection0, decoder_conv*
+
+
+def xception_blocks():
+    """(prefix, cin, filters, skip_type, last_stride, rate, depth_activation) in graph order."""
+    blocks = [
+        ("entry_flow_block1", 64, [128, 128, 128], "conv", 2, 1, False),
+        ("entry_flow_block2", 128, [256, 256, 256], "conv", 2, 1, False),
+        ("entry_flow_block3", 256, [728, 728, 728], "conv", 2, 1, False),
+    ]
+    for i in range(16):
+        blocks.append((f"middle_flow_unit_{i + 1}", 728, [728, 728, 728], "sum", 1, 1, False))
+    blocks.append(("exit_flow_block1", 728, [728, 1024, 1024], "conv", 1, 1, False))
+    blocks.append(("exit_flow_block2", 1024, [1536, 1536, 2048], None, 1, 2, True))
+    return blocks
+
+
+def layer_inventory(classes=21):
+    """Ordered list of (kind, name, shape-info dict).  kinds: conv, dw, bn."""
+    inv = []
+
+    def conv(name, kh, cin, cout, bias=False):
+        inv.append(("conv", name, dict(kh=kh, cin=cin, cout=cout, bias=bias)))
+
+    def bn(name, c, eps):
+        inv.append(("bn", name, dict(c=c, eps=eps)))
+
+    def sep(prefix, cin, cout, eps):
+        inv.append(("dw", prefix + "_depthwise", dict(c=cin)))
+        bn(prefix + "_depthwise_BN", cin, eps)
+        conv(prefix + "_pointwise", 1, cin, cout)
+        bn(prefix + "_pointwise_BN", cout, eps)
+
+    conv("entry_flow_conv1_1", 3, 3, 32)
+    bn("entry_flow_conv1_1_BN", 32, XCEPTION_BN_EPS)
+    conv("entry_flow_conv1_2", 3, 32, 64)
+    bn("entry_flow_conv1_2_BN", 64, XCEPTION_BN_EPS)
+    for prefix, cin, filters, skip, _stride, _rate, _da in xception_blocks():
+        c = cin
+        for i, f in enumerate(filters):
+            sep(f"{prefix}_separable_conv{i + 1}", c, f, XCEPTION_BN_EPS)
+            c = f
+        if skip == "conv":
+            conv(prefix + "_shortcut", 1, cin, filters[-1])
+            bn(prefix + "_shortcut_BN", filters[-1], XCEPTION_BN_EPS)
+    conv("image_pooling", 1, 2048, 256)
+    bn("image_pooling_BN", 256, HEAD_BN_EPS)
+    conv("aspp0", 1, 2048, 256)
+    bn("aspp0_BN", 256, HEAD_BN_EPS)
+    for i in (1, 2, 3):
+        sep(f"aspp{i}", 2048, 256, XCEPTION_BN_EPS)
+    conv("concat_projection", 1, 1280, 256)
+    bn("concat_projection_BN", 256, HEAD_BN_EPS)
+    conv("feature_projection0", 1, 256, 48)
+    bn("feature_projection0_BN", 48, HEAD_BN_EPS)
+    sep("decoder_conv0", 304, 256, HEAD_BN_EPS)
+    sep("decoder_conv1", 256, 256, HEAD_BN_EPS)
+    conv("logits_semantic" if classes == 21 else "custom_logits_semantic", 1, 256, classes, bias=True)
+    return inv
+
+
+def count_params(classes=21):
+    n = 0
+    for kind, _name, d in layer_inventory(classes):
+        if kind == "conv":
+            n += d["kh"] * d["kh"] * d["cin"] * d["cout"] + (d["cout"] if d["bias"] else 0)
+        elif kind == "dw":
+            n += 9 * d["c"]
+        else:
+            n += 4 * d["c"]
+    return n
+
+
+def make_synthetic_weights(seed=1234, classes=21):
+    """Seeded random parameters with variance-preserving scales so that activations stay O(1)
+    through the 65+ layers (He-style std for kernels that follow a ReLU, 1/sqrt(fan_in)
+    otherwise; BN statistics near identity; residual branches damped)."""
+    rng = np.random.default_rng(seed)
+    w = {}
+    inv = layer_inventory(classes)
+    relu_before = set()        # conv layers whose input passed through a ReLU
+    for prefix, _cin, _f, _skip, _s, _r, depth_act in xception_blocks():
+        for i in range(3):
+            p = f"{prefix}_separable_conv{i + 1}"
+            relu_before.add(p + "_depthwise" if not depth_act else p + "_pointwise")
+    for p in ("aspp1", "aspp2", "aspp3", "decoder_conv0", "decoder_conv1"):
+        relu_before.add(p + "_pointwise")
+    relu_before |= {"entry_flow_conv1_2", "aspp0", "image_pooling", "concat_projection", "logits_semantic",
+                    "custom_logits_semantic"}
+    damped = {f"middle_flow_unit_{i + 1}_separable_conv3_pointwise_BN" for i in range(16)}
+    for kind, name, d in inv:
+        if kind == "conv":
+            fan_in = d["kh"] * d["kh"] * d["cin"]
+            gain = 2.0 if name in relu_before else 1.0
+            w[name + "/kernel"] = (rng.standard_normal((d["kh"], d["kh"], d["cin"], d["cout"])) *
+                                   np.sqrt(gain / fan_in)).astype(np.float32)
+            if d["bias"]:
+                b = (rng.standard_normal(d["cout"]) * 0.1).astype(np.float32)
+                if d["cout"] > 8:
+                    b[8] += 0.8       # make the default filter class (cat, id 8) win a sizeable region
+                w[name + "/bias"] = b
+        elif kind == "dw":
+            gain = 2.0 if name in relu_before else 1.0
+            w[name + "/depthwise_kernel"] = (rng.standard_normal((3, 3, d["c"], 1)) *
+                                             np.sqrt(gain / 9.0)).astype(np.float32)
+        else:
+            c = d["c"]
+            g = rng.uniform(0.8, 1.2, c)
+            if name in damped:
+                g *= 0.3
+            w[name + "/gamma"] = g.astype(np.float32)
+            w[name + "/beta"] = (rng.standard_normal(c) * 0.05).astype(np.float32)
+            w[name + "/moving_mean"] = (rng.standard_normal(c) * 0.05).astype(np.float32)
+            w[name + "/moving_variance"] = rng.uniform(0.8, 1.2, c).astype(np.float32)
+    return w
+
+
+def save_weights(path, weights):
+    np.savez(path, **weights)
+
+
+def load_weights(path):
+    """Local .npz only (``{layer}/{variable}`` keys).  Never a URL: the reference's get_file()
+    download (model.py:134-143) has no offline counterpart."""
+    if str(path).startswith(("http://", "https://")):
+        raise ValueError("weights must be a local file; network downloads are not supported")
+    if str(path).endswith((".h5", ".hdf5")):
+        raise ValueError("HDF5 weight files need h5py, which is not available here: export the Keras weights to "
+                         ".npz with keys '<layer name>/<variable name>'")
+    with np.load(path) as z:
+        return {k: z[k] for k in z.files}
+
+
+def bn_scale_shift(weights, name, eps):
+    g = weights[name + "/gamma"].astype(np.float32)
+    b = weights[name + "/beta"].astype(np.float32)
+    m = weights[name + "/moving_mean"].astype(np.float32)
+    v = weights[name + "/moving_variance"].astype(np.float32)
+    scale = (g / np.sqrt(v + np.float32(eps))).astype(np.float32)
+    shift = (b - m * scale).astype(np.float32)
+    return scale, shift
+
+
+def fold_conv_bn(weights, conv_name, bn_name, eps):
+    """Conv2D (no bias) followed by inference BatchNorm -> ([K, cout] kernel, [cout] bias)."""
+    k = weights[conv_name + "/kernel"].astype(np.float32)
+    kh, kw, cin, cout = k.shape
+    scale, shift = bn_scale_shift(weights, bn_name, eps)
+    return (k * scale).reshape(kh * kw * cin, cout).astype(np.float32), shift
+
+
+def fold_dw_bn(weights, dw_name, bn_name, eps):
+    """DepthwiseConv2D followed by inference BatchNorm -> ([3,3,C] kernel, [C] bias)."""
+    k = weights[dw_name + "/depthwise_kernel"].astype(np.float32)[:, :, :, 0]
+    scale, shift = bn_scale_shift(weights, bn_name, eps)
+    return np.ascontiguousarray(k * scale, dtype=np.float32), shift

@@ -1,0 +1,201 @@
+/*
+ * asr_hip.h -- C ABI of libasr_hip.so: hand-written gfx950 (MI355X / CDNA4) kernels for the
+ * Augmented Super-Resolution hot path of nicoloalbergoni/DeepLabV3Plus-Augmented-SuperResolution.
+ *
+ * The reference is 100 % Python on TensorFlow 2.7 / tensorflow-addons 0.15 and has no FFI or
+ * operator-plugin interface; each entry point below replaces one (group of) stock TF/TFA/Keras
+ * op call site(s), cited as file:line relative to the reference checkout.  A Python
+ * maintainer binds them with ctypes.
+ *
+ * Conventions
+ *  - every function returns int: ASR_OK (0) or a negative ASR_ERR_*; asr_last_error() returns a
+ *    thread-local message for the last failing call on this thread;
+ *  - all array pointers are CALLER-OWNED DEVICE pointers (hipMalloc / torch ROCm tensors); the
+ *    library allocates nothing and keeps no global mutable state (callable from several host
+ *    threads / streams concurrently); scratch space is passed in explicitly;
+ *  - every call takes an explicit stream (hipStream_t passed as void*) and is asynchronous
+ *    with respect to the host;
+ *  - layouts are dense row-major float32, images NHWC; "ld*" arguments are the element stride
+ *    between consecutive pixels (>= channels) so outputs can land inside concat buffers;
+ *  - projective transforms are 8 floats [a0,a1,a2,b0,b1,b2,c0,c1] exactly as
+ *    ImageProjectiveTransformV3 takes them (output pixel (x,y) reads input at
+ *    ((a0 x + a1 y + a2)/k, (b0 x + b1 y + b2)/k), k = c0 x + c1 y + 1), BILINEAR, out-of-range
+ *    taps read 0.
+ */
+#ifndef ASR_HIP_H
+#define ASR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ASR_ABI_VERSION 1
+
+#define ASR_OK 0
+#define ASR_ERR_INVALID_ARG (-1)
+#define ASR_ERR_UNSUPPORTED (-2)
+#define ASR_ERR_HIP (-3)
+#define ASR_ERR_WORKSPACE (-4)
+
+typedef void* asr_stream_t; /* hipStream_t */
+
+const char* asr_last_error(void);
+int asr_abi_version(void);
+const char* asr_target_arch(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Augmentation / warps
+ * ------------------------------------------------------------------------------------------ */
+
+/* One ImageProjectiveTransformV3 pass.  Replaces tfa.image.rotate / tfa.image.translate
+ * (superresolution_scripts/augmentation_utils.py:22-25, superresolution.py:61-64,142-147).
+ * src [n or 1, h_in, w_in, c] (src_batched = 0: one shared source), transforms [n or 1, 8]
+ * (tf_batched = 0: one shared transform), dst [n, h_out, w_out, c]. */
+int asr_warp_affine_f32(const float* src, float* dst, const float* transforms, int n, int src_batched,
+                        int tf_batched, int h_in, int w_in, int h_out, int w_out, int c, asr_stream_t stream);
+
+/* copies[i] = translate(rotate(image, rot_tf[i]), trans_tf[i]) -- tile + two bilinear resamplings
+ * fused (superresolution_scripts/augmentation_utils.py:12-25 create_augmented_copies; :46-54
+ * chunked variant).  image [h,w,c] (c = 1 or 3), copies [n,h,w,c], rot_tf / trans_tf [n,8]. */
+int asr_augment_copies_f32(const float* image, float* copies, const float* rot_tf, const float* trans_tf, int n,
+                           int h, int w, int c, asr_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Super-resolution solver (superresolution_scripts/superresolution.py, optimizer.py)
+ * x [batch,H,W]; y / resid [batch,n,h,w]; transforms [batch,n,8]; H = f*h, W = f*w, f even.
+ * ------------------------------------------------------------------------------------------ */
+
+/* x = tf.image.resize(y[:, 0], (H, W)) -- superresolution.py:112-113. */
+int asr_sr_init_target_f32(const float* y, float* x, int batch, int n, int H, int W, int h, int w,
+                           asr_stream_t stream);
+
+/* resid[b,i] = resize(translate(rotate(tile(x_b), rot_tf), trans_tf), (h,w))[i] - y[b,i]
+ * -- the forward model of loss_function, superresolution.py:58-72. */
+int asr_sr_forward_residual_f32(const float* x, const float* y, const float* rot_tf, const float* trans_tf,
+                                float* resid, int batch, int n, int H, int W, int h, int w, asr_stream_t stream);
+
+/* One optimiser step: gradient of the loss (TensorFlow's registered gradients: SquaredDifference,
+ * ResizeBilinearGrad, ImageProjectiveTransformV3 gradient = inverse warp with inv_*_tf, Tile
+ * sum; TV / L2 / L1 priors, superresolution.py:71-98,133) followed by the Keras Adam / AMSGrad
+ * update (optimizer.py:37-41, superresolution.py:134-135).  alphas [batch] =
+ * lr_t * sqrt(1 - beta2^t) / (1 - beta1^t) per image.  x_new must not alias x.  grad_out
+ * (optional) receives the raw gradient; with x_new == NULL only grad_out is produced. */
+int asr_sr_backward_adam_f32(const float* x, float* x_new, const float* resid, const float* inv_rot_tf,
+                             const float* inv_trans_tf, float* m, float* v, float* vhat, const float* alphas,
+                             float* grad_out, int batch, int n, int H, int W, int h, int w, float lambda_df,
+                             float lambda_tv, float lambda_l2, float lambda_l1, float one_minus_beta1,
+                             float one_minus_beta2, float epsilon, int amsgrad, asr_stream_t stream);
+
+/* terms[b] = {sum resid^2, TV(x), sum x^2, sum |x|} in float64 -- the pieces of the scalar loss
+ * of superresolution.py:71-98 (reporting only). */
+int asr_sr_loss_terms_f64(const float* x, const float* resid, double* terms, int batch, int n, int H, int W, int h,
+                          int w, asr_stream_t stream);
+
+size_t asr_sr_solve_workspace_bytes(int batch, int n, int H, int W, int h, int w);
+
+/* The whole loop of augmented_superresolution (superresolution.py:120-135): num_iter x
+ * {forward residual, backward + Adam}.  x holds the initial target on entry and the result on
+ * exit; m / v / vhat [batch,H,W] are the optimiser slots (zero for a fresh variable); alphas
+ * [num_iter, batch] (device); last_loss_terms [batch,4] float64 (optional) receives the loss
+ * pieces of the last iteration, evaluated before its update like the reference's `loss`. */
+int asr_sr_solve_f32(float* x, const float* y, const float* rot_tf, const float* trans_tf, const float* inv_rot_tf,
+                     const float* inv_trans_tf, float* m, float* v, float* vhat, const float* alphas, int num_iter,
+                     double* last_loss_terms, void* workspace, size_t workspace_bytes, int batch, int n, int H, int W,
+                     int h, int w, float lambda_df, float lambda_tv, float lambda_l2, float lambda_l1,
+                     float one_minus_beta1, float one_minus_beta2, float epsilon, int amsgrad, asr_stream_t stream);
+
+/* out[b] = max / mean over copies of rotate(translate(resize(y[b,i], (H,W)), trans_tf), rot_tf)
+ * -- max_superresolution / mean_superresolution, superresolution.py:139-161 (trans_tf built
+ * from -shifts, rot_tf from -angles).  out [batch,H,W]. */
+int asr_realign_max_f32(const float* y, float* out, const float* trans_tf, const float* rot_tf, int batch, int n,
+                        int H, int W, int h, int w, asr_stream_t stream);
+int asr_realign_mean_f32(const float* y, float* out, const float* trans_tf, const float* rot_tf, int batch, int n,
+                         int H, int W, int h, int w, asr_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Output processing, thresholding, IoU
+ * ------------------------------------------------------------------------------------------ */
+
+/* out_minmax[s] = {min, max} of segment s (tf.reduce_min / tf.reduce_max,
+ * augmentation_utils.py:100-101, superres_utils.py:134). */
+int asr_minmax_f32(const float* x, float* out_minmax, int64_t per_segment, int segments, asr_stream_t stream);
+
+/* create_mask: argmax over the class axis, first maximum wins (utils.py:115-119). */
+int asr_argmax_i32(const float* logits, int32_t* out, int64_t pixels, int classes, asr_stream_t stream);
+
+/* argmax OPM: class_id where argmax == class_id else 0, as float32 (augmentation_utils.py:106-113). */
+int asr_opm_argmax_f32(const float* logits, float* class_mask, int64_t pixels, int classes, int class_id,
+                       asr_stream_t stream);
+
+/* slice_max OPM: class logit and max over the other classes (augmentation_utils.py:82-93). */
+int asr_opm_slice_max_f32(const float* logits, float* class_mask, float* max_mask, int64_t pixels, int classes,
+                          int class_id, asr_stream_t stream);
+
+/* slice OPM: class logit min-max normalised with the copy's global min / max over all classes
+ * (augmentation_utils.py:95-104 + superres_utils.py:56-62).  minmax_ws: [copies,2] floats. */
+int asr_opm_slice_f32(const float* logits, float* class_mask, float* minmax_ws, int copies, int64_t pixels_per_copy,
+                      int classes, int class_id, float new_min, float new_max, asr_stream_t stream);
+
+/* threshold_image (superres_utils.py:118-139): out = image >= th_mask ? th_value : 0, or
+ * (th_mask == NULL) image > th_factor * max(image) ? th_value : 0 per segment.
+ * minmax_ws: [segments,2] floats (needed when th_mask == NULL). */
+int asr_threshold_f32(const float* image, const float* th_mask, float* minmax_ws, int32_t* out, int64_t per_segment,
+                      int segments, float th_factor, int th_value, asr_stream_t stream);
+
+/* single_class_IOU integer counts (utils.py:180-204): counts[s] = {inter_c, union_c, inter_bg,
+ * union_bg}; with include_bg the truth is first remapped (truth != class_id -> 0).  Void (255)
+ * pixels are not excluded, exactly like the reference. */
+int asr_iou_counts_i32(const int32_t* truth, const int32_t* pred, int64_t* counts, int64_t per_segment, int segments,
+                       int class_id, int include_bg, asr_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * DeepLabV3+ (Xception-65, OS16) layers -- model.py.  BatchNorm is folded by the caller.
+ * ------------------------------------------------------------------------------------------ */
+
+/* Packed-weight size (floats) and packing for the MFMA GEMM: w_kn [k,n] row-major (a Keras
+ * HWIO kernel reshaped to [kh*kw*cin, cout]) -> private layout [ceil32(k)/4][ceil128(n)][4]. */
+size_t asr_pwconv_packed_floats(int k, int n);
+int asr_pwconv_pack_weights_f32(const float* w_kn, float* w_packed, int k, int n, asr_stream_t stream);
+
+/* Conv2D 1x1 (+ folded BN bias, optional ReLU, optional residual Add) on FP32 MFMA:
+ * y[r, :n] = act(x[row(r), :k] @ W + bias) + residual[r, :n].  Replaces every pointwise
+ * Conv2D + BatchNormalization (+ ReLU / Add) group of model.py (:195-231, :244-247, :303-304,
+ * :403-417, :500-506).  sub_stride > 1: rows are gathered at (b, s*oy, s*ox) of an
+ * h_in x w_in map -- the stride-2 1x1 shortcut of _conv2d_same (model.py:529-541).
+ * k % 4 == 0, ldx % 4 == 0. */
+int asr_pwconv_mfma_f32(const float* x, const float* w_packed, const float* bias, const float* residual, float* y,
+                        int64_t m, int k, int n, int ldx, int ldy, int ldres, int relu, int sub_stride, int h_in,
+                        int w_in, asr_stream_t stream);
+
+/* Conv2D 3x3 as implicit GEMM on FP32 MFMA (cin % 32 == 0): entry_flow_conv1_2, model.py:155-159. */
+int asr_conv3x3_mfma_f32(const float* x, const float* w_packed, const float* bias, float* y, int batch, int h_in,
+                         int w_in, int cin, int cout, int stride, int pad, int dil, int h_out, int w_out, int ldx,
+                         int ldy, int relu, asr_stream_t stream);
+
+/* Conv2D 3x3 for tiny cin, weights HWIO [3,3,cin,cout]: entry_flow_conv1_1, model.py:150-153
+ * ('same' with stride 2 on an even input pads bottom/right only: pad_top = pad_left = 0). */
+int asr_conv3x3_direct_f32(const float* x, const float* w, const float* bias, float* y, int batch, int h_in, int w_in,
+                           int cin, int cout, int stride, int pad_top, int pad_left, int h_out, int w_out, int ldx,
+                           int ldy, int relu, asr_stream_t stream);
+
+/* DepthwiseConv2D 3x3 (+ ZeroPadding2D, folded BN, ReLU before and/or after): the depthwise half
+ * of _SepConv_BN, model.py:478-495.  w [3,3,c] with the BN scale folded, bias [c].
+ * force_direct != 0 selects the untiled kernel (testing). */
+int asr_dwconv3x3_nhwc_f32(const float* x, const float* w, const float* bias, float* y, int batch, int h_in,
+                           int w_in, int c, int stride, int rate, int pad_top, int pad_left, int h_out, int w_out,
+                           int ldx, int ldy, int pre_relu, int post_relu, int force_direct, asr_stream_t stream);
+
+/* GlobalAveragePooling2D(keepdims=True): y[b, :c] = mean over hw pixels (model.py:196-197). */
+int asr_gap_f32(const float* x, float* y, int batch, int hw, int c, int ldx, asr_stream_t stream);
+
+/* Resizing(bilinear) / tf.image.resize, half-pixel centres (model.py:109-110, 204-205, 241-242). */
+int asr_resize_bilinear_f32(const float* x, float* y, int batch, int h_in, int w_in, int c, int h_out, int w_out,
+                            int ldx, int ldy, asr_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ASR_HIP_H */

@@ -1,0 +1,168 @@
+"""GPU parity of the DeepLabV3+ layer kernels (through the C ABI) against plain torch-CPU float32 /
+float64 references of the same op.  Tolerances: f32 MFMA == k-ordered fmaf chain, so GEMM-like
+outputs are compared with rtol 1e-4 / atol 1e-4 against a float64 reference (K <= 2048, O(1)
+operands); memory-bound layers with atol 1e-5."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import tf_ops
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand(rng, *shape, scale=1.0):
+    return (rng.standard_normal(shape) * scale).astype(np.float32)
+
+
+@pytest.mark.parametrize("m,k,n,relu,res", [
+    (1000, 728, 728, False, True),     # middle-flow shape, M tail, N not a multiple of 128
+    (256, 32, 21, False, False),       # logits-like, N < 32
+    (300, 304, 48, True, False),       # decoder concat K, N = 48
+    (384, 2048, 256, True, False),     # ASPP
+    (130, 64, 128, False, False),      # K = 2 tiles, tiny M tail
+    (512, 1280, 256, True, False),
+])
+def test_pwconv_matches_reference(dev, m, k, n, relu, res):
+    from asr_amd import ops
+    rng = np.random.default_rng(m + k + n)
+    x = _rand(rng, m, k)
+    w = _rand(rng, k, n, scale=1.0 / np.sqrt(k))
+    b = _rand(rng, n)
+    r = _rand(rng, m, n) if res else None
+    ref = x.astype(np.float64) @ w.astype(np.float64) + b
+    if relu:
+        ref = np.maximum(ref, 0)
+    if res:
+        ref = ref + r
+    wp = ops.pack_pw_weights(ops.to_device(w))
+    got = ops.pwconv(ops.to_device(x), wp, ops.to_device(b), k, n, relu=relu,
+                     residual=ops.to_device(r) if res else None).cpu().numpy()
+    np.testing.assert_allclose(got, ref, rtol=1e-4, atol=1e-4)
+
+
+def test_pwconv_asymmetric_identity(dev):
+    """A = I with an asymmetric B catches a transposed C-write or a wrong k permutation exactly."""
+    from asr_amd import ops
+    k = n = 160
+    x = np.eye(k, dtype=np.float32)
+    w = (np.arange(k * n, dtype=np.float32).reshape(k, n) % 251) - 100.0
+    got = ops.pwconv(ops.to_device(x), ops.pack_pw_weights(ops.to_device(w)), None, k, n).cpu().numpy()
+    assert np.array_equal(got, w)
+
+
+def test_pwconv_strided_rows_and_concat_output(dev):
+    """stride-2 shortcut gather (model.py:529-541) writing into a channel slice of a wider buffer."""
+    from asr_amd import ops, _lib
+    rng = np.random.default_rng(11)
+    b, h, w_, k, n = 2, 12, 10, 64, 40
+    x = _rand(rng, b, h, w_, k)
+    wt = _rand(rng, k, n, scale=0.1)
+    bias = _rand(rng, n)
+    ho, wo = 6, 5
+    ref = x[:, ::2, ::2].reshape(-1, k).astype(np.float64) @ wt.astype(np.float64) + bias
+    total_c = 72
+    out = torch.full((b * ho * wo, total_c), -7.0, device=dev)
+    xd, wp, bd = ops.to_device(x), ops.pack_pw_weights(ops.to_device(wt)), ops.to_device(bias)
+    _lib.call("asr_pwconv_mfma_f32", xd.data_ptr(), wp.data_ptr(), bd.data_ptr(), None, out.data_ptr() + 4 * 16,
+              b * ho * wo, k, n, k, total_c, 0, 0, 2, h, w_, _lib.stream_ptr())
+    got = out.cpu().numpy()
+    np.testing.assert_allclose(got[:, 16:16 + n], ref, rtol=1e-4, atol=1e-4)
+    assert np.all(got[:, :16] == -7.0) and np.all(got[:, 16 + n:] == -7.0)
+
+
+def test_conv3x3_mfma_matches_conv2d(dev):
+    from asr_amd import ops
+    rng = np.random.default_rng(12)
+    b, h, w_, cin, cout = 2, 20, 28, 32, 64
+    x = _rand(rng, b, h, w_, cin)
+    k = _rand(rng, 3, 3, cin, cout, scale=0.08)
+    bias = _rand(rng, cout)
+    ref = F.conv2d(torch.from_numpy(x).permute(0, 3, 1, 2).double(), torch.from_numpy(k).permute(3, 2, 0, 1).double(),
+                   torch.from_numpy(bias).double(), padding=1).relu().permute(0, 2, 3, 1).numpy()
+    wp = ops.pack_pw_weights(ops.to_device(k.reshape(9 * cin, cout)))
+    got = ops.conv3x3_mfma(ops.to_device(x), wp, ops.to_device(bias), cout, relu=True).cpu().numpy()
+    np.testing.assert_allclose(got, ref, rtol=1e-4, atol=1e-4)
+
+
+def test_conv3x3_direct_same_padding_stride2(dev):
+    """entry_flow_conv1_1: 'same' + stride 2 on an even input pads bottom/right only."""
+    from asr_amd import ops
+    rng = np.random.default_rng(13)
+    b, h, w_, cin, cout = 2, 32, 48, 3, 32
+    x = _rand(rng, b, h, w_, cin)
+    k = _rand(rng, 3, 3, cin, cout, scale=0.3)
+    bias = _rand(rng, cout)
+    xt = F.pad(torch.from_numpy(x).permute(0, 3, 1, 2), (0, 1, 0, 1))
+    ref = F.conv2d(xt, torch.from_numpy(k).permute(3, 2, 0, 1), torch.from_numpy(bias), stride=2).relu()
+    ref = ref.permute(0, 2, 3, 1).numpy()
+    got = ops.conv3x3_direct(ops.to_device(x), ops.to_device(k), ops.to_device(bias), 2, 0, 0, (h // 2, w_ // 2),
+                             relu=True).cpu().numpy()
+    np.testing.assert_allclose(got, ref, rtol=1e-5, atol=1e-5)
+    # impulse at the last pixel only reaches the last output pixel (asymmetric padding check)
+    imp = np.zeros((1, 8, 8, 3), np.float32)
+    imp[0, 7, 7, 0] = 1.0
+    g = ops.conv3x3_direct(ops.to_device(imp), ops.to_device(k), ops.to_device(np.zeros(cout, np.float32)), 2, 0, 0,
+                           (4, 4)).cpu().numpy()
+    assert np.count_nonzero(np.abs(g).sum(-1)) == 1 and np.allclose(g[0, 3, 3], k[1, 1, 0])
+
+
+def _dw_ref(x, k, bias, stride, rate, pad, pre, post):
+    xt = torch.from_numpy(x).permute(0, 3, 1, 2)
+    if pre:
+        xt = xt.relu()
+    xt = F.pad(xt, (pad[2], pad[3], pad[0], pad[1]))
+    c = x.shape[-1]
+    y = F.conv2d(xt, torch.from_numpy(k).permute(2, 0, 1)[:, None], torch.from_numpy(bias), stride=stride,
+                 dilation=rate, groups=c)
+    if post:
+        y = y.relu()
+    return y.permute(0, 2, 3, 1).numpy()
+
+
+@pytest.mark.parametrize("h,w_,c,stride,rate,pre,post,direct", [
+    (32, 32, 728, 1, 1, True, False, False),     # middle flow, C not a multiple of 64
+    (40, 24, 128, 1, 1, True, False, False),     # ragged tiles
+    (32, 32, 1536, 1, 2, False, True, False),    # exit block 2
+    (32, 32, 256, 1, 1, False, True, True),      # direct kernel, same result
+    (64, 64, 128, 2, 1, True, False, False),     # stride-2 block end (explicit pad 1,1)
+    (32, 32, 2048, 1, 6, False, True, False),    # ASPP
+    (32, 32, 512, 1, 12, False, True, False),
+    (32, 32, 512, 1, 18, False, True, False),
+    (9, 7, 8, 1, 1, False, False, False),        # tiny
+])
+def test_dwconv_matches_conv2d(dev, h, w_, c, stride, rate, pre, post, direct):
+    from asr_amd import ops
+    rng = np.random.default_rng(h * 7 + c + rate)
+    b = 2
+    x = _rand(rng, b, h, w_, c)
+    k = _rand(rng, 3, 3, c, scale=0.3)
+    bias = _rand(rng, c)
+    if stride == 1:
+        pad = (rate, rate, rate, rate)
+        out_hw = (h, w_)
+    else:
+        pad = (1, 1, 1, 1)                       # ZeroPadding2D((1,1)), model.py:480-486
+        out_hw = ((h + 2 - 3) // 2 + 1, (w_ + 2 - 3) // 2 + 1)
+    ref = _dw_ref(x, k, bias, stride, rate, pad, pre, post)
+    got = ops.dwconv3x3(ops.to_device(x), ops.to_device(k), ops.to_device(bias), stride=stride, rate=rate,
+                        pad_top=pad[0], pad_left=pad[2], out_hw=out_hw, pre_relu=pre, post_relu=post,
+                        force_direct=direct).cpu().numpy()
+    assert got.shape == ref.shape
+    np.testing.assert_allclose(got, ref, rtol=1e-5, atol=2e-5)
+
+
+def test_gap_and_resize(dev):
+    from asr_amd import ops
+    rng = np.random.default_rng(14)
+    x = _rand(rng, 3, 32, 32, 2048)
+    got = ops.gap(ops.to_device(x)).cpu().numpy()
+    np.testing.assert_allclose(got, x.astype(np.float64).mean(axis=(1, 2)), rtol=1e-5, atol=1e-6)
+    y = _rand(rng, 2, 8, 8, 256)
+    ref = tf_ops.resize_bilinear(torch.from_numpy(y), (32, 32)).numpy()
+    got = ops.resize_bilinear(ops.to_device(y), (32, 32)).cpu().numpy()
+    np.testing.assert_allclose(got, ref, rtol=0, atol=1e-6)
+    one = _rand(rng, 2, 1, 1, 256)               # image-pooling broadcast (model.py:204-205)
+    got = ops.resize_bilinear(ops.to_device(one), (16, 16)).cpu().numpy()
+    assert np.array_equal(got, np.broadcast_to(one, (2, 16, 16, 256)))

@@ -1,0 +1,95 @@
+"""GPU parity of the fused DeepLabV3+ engine against the unfused layer-by-layer torch-CPU oracle,
+with the same seeded synthetic weights, and of the whole hot path through the reference-shaped
+Python surface (config 1 of BASELINE.json: test_cat.jpg, num_aug=8, argmax OPM, class 8)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import augment as o_aug
+from oracle import sr as o_sr
+from oracle.model import OracleDeeplabV3Plus
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def synthetic():
+    from asr_amd import weights as W
+    return W.make_synthetic_weights(seed=1234, classes=21)
+
+
+def test_engine_logits_match_oracle(dev, synthetic):
+    from asr_amd.model import DeeplabModel
+    rng = np.random.default_rng(21)
+    x = rng.random((3, 64, 96, 3), dtype=np.float32)
+    ref = OracleDeeplabV3Plus(synthetic).forward(x)
+    model = DeeplabModel(synthetic, (64, 96, 3), 21, final_upsample=False, last_activation=None)
+    got = model.predict(x, batch_size=2)                      # 2 + 1: exercises two plans
+    assert got.shape == ref.shape == (3, 16, 24, 21)
+    scale = np.abs(ref).max()
+    # float32 end to end, BN folded and ReLU/Add fused: differences are rounding only
+    np.testing.assert_allclose(got, ref, rtol=0, atol=2e-4 * scale)
+    agree = (got.argmax(-1) == ref.argmax(-1)).mean()
+    assert agree >= 0.999, agree
+
+
+def test_final_upsample_matches_oracle(dev, synthetic):
+    from asr_amd.model import DeeplabModel
+    rng = np.random.default_rng(22)
+    x = rng.random((1, 64, 64, 3), dtype=np.float32)
+    ref = OracleDeeplabV3Plus(synthetic).forward(x, final_upsample=True)
+    got = DeeplabModel(synthetic, (64, 64, 3), 21, True, None).predict(x)
+    np.testing.assert_allclose(got, ref, rtol=0, atol=2e-4 * np.abs(ref).max())
+
+
+def test_hot_path_config1_test_cat(dev, synthetic, golden_dir, tmp_path):
+    """test_SR.py flow on the bundled sample at 256x256 (oracle-sized): same seed -> same
+    angles/shifts; masks from the HIP path vs the oracle path; IoU within 1e-3 (north_star bar)."""
+    from asr_amd.model import DeeplabModel
+    from asr_amd.utils import load_image, compute_IoU
+    from asr_amd.superresolution_scripts.optimizer import Optimizer
+    from asr_amd.superresolution_scripts.superresolution import Superresolution
+    from asr_amd.superresolution_scripts.augmentation_utils import compute_augmented_feature_maps
+    from asr_amd.superresolution_scripts.superres_utils import compute_SR
+
+    img_path = os.path.join(golden_dir, "test_cat.jpg")
+    gt_path = os.path.join(golden_dir, "test_cat_gt.png")
+    size, fsize, n_aug, cls, iters = (256, 256), (64, 64), 8, 8, 20
+
+    # ---- HIP path through the reference-shaped API ----
+    np.random.seed(1234)
+    model = DeeplabModel(synthetic, size + (3,), 21, False, None)
+    opt = Optimizer("adam", 1e-3, amsgrad=True, lr_scheduler=True, decay_steps=60, decay_rate=0.3)
+    sr = Superresolution(1.0, 0.3, 0.7, 0.0, num_iter=iters, num_aug=n_aug, optimizer=opt, feature_size=fsize,
+                         output_size=size)
+    masks, max_masks, angles, shifts, name = compute_augmented_feature_maps(
+        img_path, model, filter_class_id=cls, mode="argmax", num_aug=n_aug, angle_max=0.15, shift_max=40,
+        image_size=size, batch_size=4)
+    assert name == "test_cat" and len(masks) == n_aug and masks[0].shape == fsize + (1,)
+    out = {t: compute_SR(sr, masks, angles, shifts, name, str(tmp_path), SR_type=t, max_masks=max_masks,
+                         class_id=cls, th_factor=0.2) for t in ("aug", "max", "mean")}
+    gt = load_image(gt_path, image_size=size, normalize=False, is_png=True, resize_method="nearest")
+
+    # ---- oracle path, same seed ----
+    np.random.seed(1234)
+    o_img = o_aug.load_image(img_path, image_size=size)
+    o_copies, o_angles, o_shifts = o_aug.create_augmented_copies(o_img, n_aug, 0.15, 40)
+    assert np.array_equal(o_angles, angles) and np.array_equal(o_shifts, shifts)
+    o_pred = OracleDeeplabV3Plus(synthetic).predict(o_copies, batch_size=4)
+    o_masks, _ = o_aug.opm(o_pred, cls, "argmax")
+    lr_agree = np.mean([np.mean(a == b) for a, b in zip(masks, o_masks)])
+    assert lr_agree >= 0.999, lr_agree
+    o_opt = o_sr.Optimizer("adam", 1e-3, amsgrad=True, lr_scheduler=True, decay_steps=60, decay_rate=0.3)
+    o_srobj = o_sr.Superresolution(1.0, 0.3, 0.7, 0.0, num_iter=iters, num_aug=n_aug, optimizer=o_opt,
+                                   feature_size=fsize, output_size=size)
+    o_gt = o_aug.load_image(gt_path, image_size=size, normalize=False, is_png=True, resize_method="nearest")
+    assert np.array_equal(o_gt, gt)
+    for t in ("aug", "max", "mean"):
+        ref = o_sr.compute_SR(o_srobj, o_masks, o_angles, o_shifts, SR_type=t, class_id=cls, th_factor=0.2)
+        # mask-vs-mask IoU (identical augmentation seeds) and IoU-vs-GT delta, both within 1e-3
+        assert o_aug.single_class_IOU(ref, out[t], cls, False) >= 0.999 or (ref == cls).sum() == 0
+        d = abs(np.nan_to_num(compute_IoU(gt, out[t], img_size=size, class_id=cls)) -
+                np.nan_to_num(o_aug.compute_IoU(o_gt, ref, img_size=size, class_id=cls)))
+        assert d <= 1e-3, (t, d)
