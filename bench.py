@@ -1,0 +1,247 @@
+#!/usr/bin/env python3
+"""Benchmark of the Augmented Super-Resolution hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): synthetic 512x512 images, num_aug=100, angle +-0.15,
+shift +-80, argmax OPM, class 8, 50 AMSGrad SR iterations (lr 1e-3, decay 60/0.3,
+lambda = 1/.3/.7/0), plus max-SR and mean-SR, threshold and the 6 IoUs of SR_single_class.py.
+One STEP = one image = 100 augmented copies through
+    augment -> DeepLabV3+ Xception-65 forward (f32) -> OPM -> {ASR 50 iters, max-SR, mean-SR}
+    -> threshold -> IoU counts,
+with the image and its ground truth resident in HBM before the timed region.  Default K = 64
+(the whole 64-image configuration).  For N > 1 (torch.distributed.run, one rank per GPU) every
+rank processes K images of its own (weak scaling), no data-path collective, one RCCL all-gather
+of the per-image IoU records at the end (inside the timed region).
+
+Prints ONE JSON line on rank 0: metric/value (+ roofline of the dominant kernel, measured with
+HIP events on the launch stream in an extra profiled step, + cpu_baseline = the CPU oracle timed
+on the host cores on a bounded sample).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+IMG = 512
+FEAT = 128
+NUM_AUG = 100
+ANGLE_MAX = 0.15
+SHIFT_MAX = 80
+CLASS_ID = 8
+SR_ITERS = 50
+TH_FACTOR = 0.2
+F32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: FP32 matrix peak (spec), dense
+HBM_PEAK_GBS = 8000.0
+
+
+def synth_image(rng, size=IMG, box=8):
+    """U[0,1) noise low-pass filtered with a box filter so that masks have structure."""
+    x = rng.random((size + box, size + box, 3), dtype=np.float32)
+    c = np.cumsum(np.cumsum(x, axis=0), axis=1)
+    c = np.pad(c, ((1, 0), (1, 0), (0, 0)))
+    s = c[box:, box:] - c[:-box, box:] - c[box:, :-box] + c[:-box, :-box]
+    s = s[:size, :size] / (box * box)
+    s = (s - s.min()) / (s.max() - s.min())
+    return np.ascontiguousarray(s, dtype=np.float32)
+
+
+def synth_gt(rng, size=IMG):
+    """class-8 blob with a void (255) border, other pixels background."""
+    yy, xx = np.mgrid[0:size, 0:size].astype(np.float32)
+    cy, cx = size * (0.4 + 0.2 * rng.random()), size * (0.4 + 0.2 * rng.random())
+    ry, rx = size * (0.15 + 0.15 * rng.random()), size * (0.15 + 0.15 * rng.random())
+    d = ((yy - cy) / ry) ** 2 + ((xx - cx) / rx) ** 2
+    gt = np.zeros((size, size), np.int32)
+    gt[d < 1.15] = 255
+    gt[d < 1.0] = CLASS_ID
+    return gt
+
+
+def cpu_baseline(weights, seed=1234):
+    """The CPU oracle (TF-materialised formulation, torch-CPU/numpy f32) on a bounded sample of the
+    same workload: 1 image 512x512, 4 copies through the model, SR with N=4 for 2 iterations; the
+    per-copy cost is extrapolated to N=100 / 50 iterations and reported in the metric's unit."""
+    import torch
+    from oracle import augment as o_aug, sr as o_sr
+    from oracle.model import OracleDeeplabV3Plus
+    n = 4
+    iters = 2
+    rng = np.random.default_rng(seed)
+    img = synth_image(rng)
+    np.random.seed(seed)
+    t0 = time.perf_counter()
+    copies, angles, shifts = o_aug.create_augmented_copies(img, n, ANGLE_MAX, SHIFT_MAX)
+    t_aug = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    pred = OracleDeeplabV3Plus(weights).predict(copies, batch_size=n)
+    t_fwd = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    masks, _ = o_aug.opm(pred, CLASS_ID, "argmax")
+    t_opm = time.perf_counter() - t0
+    opt = o_sr.Optimizer("adam", 1e-3, amsgrad=True, lr_scheduler=True, decay_steps=60, decay_rate=0.3)
+    sr = o_sr.Superresolution(1.0, 0.3, 0.7, 0.0, num_iter=iters, num_aug=n, optimizer=opt,
+                              feature_size=(FEAT, FEAT), output_size=(IMG, IMG))
+    t0 = time.perf_counter()
+    sr.max_superresolution(masks, angles, shifts)
+    sr.mean_superresolution(masks, angles, shifts)
+    t_realign = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    sr.augmented_superresolution(masks, angles, shifts)
+    t_sr = time.perf_counter() - t0
+    per_copy = (t_aug + t_fwd + t_opm + t_realign) / n + (t_sr / (iters * n)) * SR_ITERS
+    return {
+        "value": round(1.0 / per_copy, 4), "unit": "augmented-copies/s", "cores": torch.get_num_threads(),
+        "kind": "port",
+        "sample": (f"CPU restatement of the reference (TF2 unavailable offline): 1 image 512x512, {n} copies; "
+                   f"augment {t_aug:.2f}s + model fwd {t_fwd:.2f}s + OPM {t_opm:.2f}s + max/mean-SR {t_realign:.2f}s, "
+                   f"ASR {iters} iters at N={n} {t_sr:.2f}s extrapolated to {SR_ITERS} iters per copy"),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch-size", type=int, default=int(os.environ.get("ASR_BATCH", "50")))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import __graft_entry__ as entry
+    from asr_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        entry.build()
+    from asr_amd import distributed as D, weights as W, ops
+    from asr_amd.model import DeeplabModel
+    from asr_amd.pipeline import HotPath
+    from asr_amd.superresolution_scripts.optimizer import Optimizer
+    from asr_amd.superresolution_scripts.superresolution import Superresolution
+
+    rank, world, local_rank = D.init_from_env()
+    assert world == args.gpus or world == 1, f"WORLD_SIZE={world} but --gpus {args.gpus}"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    K, Wm = args.steps, args.warmup
+    per_rank = K + Wm
+    total_images = per_rank * world
+    weights = W.make_synthetic_weights(1234, 21)
+    model = DeeplabModel(weights, (IMG, IMG, 3), 21, final_upsample=False, last_activation=None)
+    opt = Optimizer("adam", 1e-3, amsgrad=True, lr_scheduler=True, decay_steps=60, decay_rate=0.3)
+    sr = Superresolution(1.0, 0.3, 0.7, 0.0, num_iter=SR_ITERS, num_aug=NUM_AUG, optimizer=opt,
+                         feature_size=(FEAT, FEAT), output_size=(IMG, IMG))
+    path = HotPath(model, sr, class_id=CLASS_ID, mode="argmax", th_factor=TH_FACTOR, batch_size=args.batch_size)
+
+    # Synthetic inputs, resident in HBM before the timed region.  Global image g = step * world + rank;
+    # every rank replays the reference's sequential RNG stream and keeps its own draws.
+    params = D.replay_augmentation_stream(total_images, NUM_AUG, ANGLE_MAX, SHIFT_MAX, seed=1234)
+    my_globals = [s * world + rank for s in range(per_rank)]
+    distinct = min(per_rank, 8)                      # 8 distinct images per rank, cycled (content does not change the work)
+    imgs, gts = [], []
+    for j in range(distinct):
+        rng = np.random.default_rng(1234 + 1000 * rank + j)
+        imgs.append(ops.to_device(synth_image(rng), device=dev))
+        gts.append(ops.to_device(synth_gt(rng), torch.int32, device=dev))
+
+    def step(i, profile=None):
+        g = my_globals[i]
+        angles, shifts = params[g]
+        return path.run_image(imgs[i % distinct], angles, shifts, gt_dev=gts[i % distinct],
+                              adam_start=D.adam_start_step(g, SR_ITERS), profile=profile)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+
+    for i in range(Wm):
+        step(i)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    records = []
+    for i in range(Wm, Wm + K):
+        records.append(step(i)["ious"])
+    table = D.all_gather_iou(my_globals[Wm:], records, total_images, device=dev)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    copies_total = K * NUM_AUG * world
+    out = {
+        "metric": "augmented-copies/sec (fwd+realign+SR-iter) @512x512",
+        "value": round(copies_total / elapsed, 3),
+        "unit": "augmented-copies/s",
+        "n_gpus": world,
+        "steps": K,
+        "warmup": Wm,
+        "ms_per_step": round(1000.0 * elapsed / K, 3),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": ("BASELINE configs[1]: synthetic 512x512 images, num_aug=100, angle+-0.15 shift+-80, argmax OPM "
+                         "class 8, ASR 50 AMSGrad iters + max-SR + mean-SR + threshold + 6 IoUs; step = 1 image = 100 copies; "
+                         "DeepLabV3+ Xception-65 OS16 f32, seeded synthetic weights"),
+            "images_per_gpu": K, "num_aug": NUM_AUG, "sr_iters": SR_ITERS, "forward_batch": args.batch_size,
+            "parallelism": f"images sharded over {world} GPU(s), one all-gather of IoU records",
+        },
+    }
+    if rank == 0:
+        valid = table[~np.isnan(table[:, 2])]
+        out["mean_ious"] = {k: (None if np.isnan(v) else round(v, 6))
+                            for k, v in D.mean_ious(valid if len(valid) else table).items()}
+
+    # ---- roofline of the dominant kernel (pointwise FP32-MFMA GEMM), HIP events on the launch stream ----
+    if rank == 0 and not args.no_roofline:
+        prof = {}
+        step(Wm, profile=prof)
+        torch.cuda.synchronize()
+        ms, flops, nbytes, launches = prof["pw"]
+        achieved = flops / (ms * 1e-3) / 1e12
+        out["roofline"] = {
+            "kernel": "pw_gemm_kernel (asr_pwconv_mfma_f32, v_mfma_f32_32x32x2_f32)",
+            "bound": "mfma", "achieved": round(achieved, 3), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+            "launches": launches, "avg_launch_ms": round(ms / launches, 4),
+            "algorithmic_gflop_per_launch": round(flops / launches / 1e9, 3),
+            "note": "HIP events around every launch of one extra profiled step after the timed region",
+        }
+        if "dw" in prof:
+            dms, _dfl, dby, dl = prof["dw"]
+            gbs = dby / (dms * 1e-3) / 1e9
+            out["roofline_depthwise"] = {
+                "kernel": "dw_tiled_kernel / dw_direct_kernel (asr_dwconv3x3_nhwc_f32)", "bound": "hbm",
+                "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                "traffic": None, "launches": dl, "avg_launch_ms": round(dms / dl, 4),
+            }
+        out["kernel_time_ms_per_step"] = {k: round(v[0], 3) for k, v in prof.items()}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(weights)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

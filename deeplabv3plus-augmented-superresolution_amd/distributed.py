@@ -1,0 +1,96 @@
+"""Image-level sharding over the GPUs of one node and the single collective of the path.
+
+The reference is single-process: it loops over images (generate_augmented_copies.py:88-91,
+SR_single_class.py:83) appending per-image IoUs to Python lists and finishes with ``np.mean``
+(SR_single_class.py:122-134).  Images are independent, so here image i belongs to rank
+i mod world_size, with NO collective on the data path; the list-append + mean becomes ONE
+all-gather of the per-image IoU records (<= a few KB, latency-bound) over RCCL/xGMI
+(``backend="nccl"`` is RCCL on ROCm; ``gloo`` on CPU for tests).
+
+Identical augmentation seeds under sharding: every rank replays the reference's sequential numpy
+RNG stream for ALL images and keeps its own slice; the reference's persistent Adam step counter
+ is reproduced by seeding ``iterations = image_index * num_iter * solves_per_image``.
+"""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from .superresolution_scripts.augmentation_utils import draw_augmentation_parameters
+
+IOU_FIELDS = ("standard_single", "standard_bg", "aug_single", "aug_bg", "max", "mean")
+
+
+def init_from_env(backend=None):
+    """One process per GPU, launched by torch.distributed.run.  Returns (rank, world, local_rank)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local_rank
+
+
+def shard_indices(num_images, rank, world):
+    """Global image indices owned by ``rank`` (round-robin, like dealing the reference's loop)."""
+    return list(range(rank, num_images, world))
+
+
+def replay_augmentation_stream(num_images, num_aug, angle_max, shift_max, seed=1234):
+    """The (angles, shifts) every image would get from the reference's sequential global RNG
+    (np.random.seed once at import, generate_augmented_copies.py:41-44)."""
+    state = np.random.get_state()
+    try:
+        np.random.seed(seed)
+        out = [draw_augmentation_parameters(num_aug, angle_max, shift_max) for _ in range(num_images)]
+    finally:
+        np.random.set_state(state)
+    return out
+
+
+def adam_start_step(image_index, num_iter, mode="argmax"):
+    """Global Adam ``iterations`` before the reference's solve of image ``image_index``."""
+    return image_index * num_iter * (2 if mode == "slice_max" else 1)
+
+
+def all_gather_iou(local_indices, local_records, num_images, device=None):
+    """local_records: [n_local, 6] float64 IoUs of the images in local_indices.  Returns the full
+    [num_images, 6] table (NaN where no rank reported) on every rank via one all_gather."""
+    rec = np.asarray(local_records, dtype=np.float64).reshape(-1, len(IOU_FIELDS))
+    idx = np.asarray(local_indices, dtype=np.int64)
+    assert rec.shape[0] == idx.shape[0]
+    table = np.full((num_images, len(IOU_FIELDS)), np.nan)
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        table[idx] = rec
+        return table
+    world = dist.get_world_size()
+    cap = -(-num_images // world)                       # equal-sized slots: ceil(images / world)
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    slot = torch.full((cap, 1 + len(IOU_FIELDS)), -1.0, dtype=torch.float64)
+    slot[:len(idx), 0] = torch.from_numpy(idx.astype(np.float64))
+    slot[:len(idx), 1:] = torch.from_numpy(rec)
+    slot = slot.to(device)
+    gathered = [torch.empty_like(slot) for _ in range(world)]
+    dist.all_gather(gathered, slot)
+    for g in gathered:
+        g = g.cpu().numpy()
+        valid = g[:, 0] >= 0
+        table[g[valid, 0].astype(np.int64)] = g[valid, 1:]
+    return table
+
+
+def mean_ious(table):
+    """np.mean over images of each IoU column (SR_single_class.py:129-134); like the reference, a NaN
+    per-image IoU (class absent from both masks) makes that column's mean NaN."""
+    return {k: float(np.mean(table[:, i])) for i, k in enumerate(IOU_FIELDS)}

@@ -1,0 +1,103 @@
+"""The whole hot path for one image, device-resident end to end:
+
+    augment (N copies) -> DeepLabV3+ forward -> OPM -> {ASR solve, max-SR, mean-SR} -> threshold
+    -> IoU counts
+
+i.e. the body of test_SR.py:73-94 / generate_augmented_copies.py:88-91 + SR_single_class.py:83-127
+without the host round trips (ndarray lists, HDF5) the reference puts between the stages.
+Used by bench.py, the scripts and the smoke test.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import ops
+from .superresolution_scripts import augmentation_utils as au
+from .utils import iou_from_counts
+
+
+class HotPath:
+    def __init__(self, model, superresolution, class_id=8, mode="argmax", th_factor=0.15, batch_size=16):
+        self.model = model
+        self.sr = superresolution
+        self.class_id = class_id
+        self.mode = mode
+        self.th_factor = th_factor
+        self.batch_size = batch_size
+
+    def _threshold(self, target, target_max):
+        if target_max is not None:
+            return ops.threshold(target, self.class_id, th_mask=target_max)
+        return ops.threshold(target, self.class_id, th_factor=self.th_factor)
+
+    def standard_mask(self, logits0, out_hw):
+        """generate_standard_output.py:52-65: final bilinear upsample + argmax + class filter, from the
+        logits of the un-augmented copy 0."""
+        h, w, c = logits0.shape
+        cp = (c + 3) // 4 * 4
+        padded = torch.full((1, h, w, cp), -3.0e38, dtype=torch.float32, device=logits0.device)
+        padded[0, :, :, :c] = logits0
+        up = ops.resize_bilinear(padded, out_hw)
+        am = ops.argmax(up)[0]
+        return torch.where(am == self.class_id, am, torch.zeros_like(am))
+
+    def run_image(self, image_dev, angles, shifts, gt_dev=None, adam_start=None, profile=None,
+                  sr_types=("aug", "max", "mean"), want_standard=True):
+        """image_dev [H,W,3] float32 device; angles [N], shifts [N,2] float32 host arrays;
+        gt_dev [H,W] int32 device labels (optional).  Returns dict of device masks (+ 6 IoUs)."""
+        sr = self.sr
+        out_hw = sr.output_size
+        copies = au.augment_on_device(image_dev, angles, shifts)
+        preds = self.model.predict_device(copies, batch_size=self.batch_size, profile=profile)
+        del copies
+        cls, mx = au.output_processing(preds, self.class_id, self.mode)
+        res = {}
+        if want_standard:
+            res["standard"] = self.standard_mask(preds[0], out_hw)
+        del preds
+        y = cls[None]
+        ymax = mx[None] if mx is not None else None
+        a, s = angles[None], shifts[None]
+        if self.mode != "slice":            # load_SR_data's global min-max normalisation (superres_utils.py:183-192)
+            y = self._normalise(y)
+            if ymax is not None:
+                ymax = self._normalise(ymax)
+        for t in sr_types:
+            if t == "aug":
+                if adam_start is not None:
+                    sr.optimizer.optimizer.iterations = adam_start
+                tgt, _ = sr.augmented_superresolution_batch(y, a, s)
+                tmax = sr.augmented_superresolution_batch(ymax, a, s)[0] if ymax is not None else None
+            else:
+                tgt = sr.realign_batch(y, a, s, t)
+                tmax = sr.realign_batch(ymax, a, s, t) if ymax is not None else None
+            res[t] = self._threshold(tgt[0], tmax[0] if tmax is not None else None)
+        if gt_dev is not None:
+            res["ious"] = self.iou_record(res, gt_dev)
+        return res
+
+    @staticmethod
+    def _normalise(stack):
+        mm = ops.minmax(stack.contiguous())[0]
+        den = mm[1] - mm[0]
+        den = torch.where(den != 0, den, torch.ones_like(den))
+        return ((stack - mm[0]) / den).contiguous()
+
+    def iou_record(self, res, gt_dev):
+        """[standard_single, standard_bg, aug_single, aug_bg, max, mean] (SR_single_class.py:109-120);
+        one small D2H copy of the integer counts."""
+        cid = self.class_id
+        gt = gt_dev.reshape(-1).to(torch.int32)
+        keys = [k for k in ("standard", "aug", "max", "mean") if k in res]
+        preds = torch.stack([res[k].reshape(-1).to(torch.int32) for k in keys])
+        truth = gt[None].expand(len(keys), -1).contiguous()
+        counts = ops.iou_counts(truth, preds, cid, include_bg=True, segments=len(keys)).cpu().numpy()
+        by = dict(zip(keys, counts))
+        nan = float("nan")
+
+        def iou(k, bg):
+            return iou_from_counts(by[k], bg) if k in by else nan
+
+        return np.array([iou("standard", False), iou("standard", True), iou("aug", False), iou("aug", True),
+                         iou("max", False), iou("mean", False)], dtype=np.float64)
