@@ -234,7 +234,7 @@ def main():
                 "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
                 "traffic": None, "launches": dl, "avg_launch_ms": round(dms / dl, 4),
             }
-        out["kernel_time_ms_per_step"] = {k: round(v[0], 3) for k, v in prof.items()}
+        out["kernel_time_ms_per_step"] = {k: round(v[0], 3) for k, v in prof.items() if not k.startswith("_")}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(weights)
     if rank == 0:

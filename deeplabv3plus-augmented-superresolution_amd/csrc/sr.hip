@@ -83,6 +83,39 @@ struct AdamArgs {
     int amsgrad;
 };
 
+// One axis of the inverse-translate stage for one integer G_R coordinate c (pure translation:
+// the map is c + shift exactly, so x and y separate).  Bitwise the same values the generic
+// asr_tf_sample path produces, computed once per axis instead of once per tap.
+struct SrAxisTap {
+    float wl, wh;   // (c_ceil - pos), (pos - c_floor)
+    int l0, l1;     // LR index of the two G_T taps, or -1 when that tap is structurally zero
+    bool inb;       // c itself inside the image (else G_R(c) = 0)
+};
+
+template <int LOG2F>
+__device__ __forceinline__ int sr_gt_index(int t, int size, int f, int ph0, int ph1) {
+    // G_T = ResizeBilinearGrad(g_D) is non-zero only on the 2x2 centre of every f x f block
+    if (t < 0 || t >= size) return -1;
+    const int ph = (LOG2F > 0) ? (t & (f - 1)) : (t % f);
+    if (ph != ph0 && ph != ph1) return -1;
+    return (LOG2F > 0) ? (t >> LOG2F) : (t / f);
+}
+
+template <int LOG2F>
+__device__ __forceinline__ SrAxisTap sr_axis_tap(int c, float shift, int size, int f, int ph0, int ph1) {
+    SrAxisTap a;
+    a.inb = (c >= 0 && c < size);
+    const float pos = (float)c + shift;
+    const float fl = floorf(pos);
+    a.wl = (fl + 1.0f) - pos;
+    a.wh = pos - fl;
+    const int t0 = asr_coord_to_int(fl);
+    a.l0 = sr_gt_index<LOG2F>(t0, size, f, ph0, ph1);
+    a.l1 = sr_gt_index<LOG2F>(t0 + 1, size, f, ph0, ph1);
+    return a;
+}
+
+template <int LOG2F>
 __global__ __launch_bounds__(256) void sr_backward_adam_kernel(
     const float* __restrict__ x, float* __restrict__ x_new, const float* __restrict__ resid,
     const float* __restrict__ inv_rot_tf, const float* __restrict__ inv_trans_tf,
@@ -102,18 +135,42 @@ __global__ __launch_bounds__(256) void sr_backward_adam_kernel(
         const float* r = resid + (int64_t)bn * lh * lw;
         const AsrTf8 ir = asr_load_tf(inv_rot_tf + (int64_t)bn * 8);
         const AsrTf8 it = asr_load_tf(inv_trans_tf + (int64_t)bn * 8);
-        // G_T = ResizeBilinearGrad(2*lambda*resid): only the 2x2 centre of each f x f block
-        auto rd_gt = [&](int yt, int xt) -> float {
-            if (!(yt >= 0 && yt < H && xt >= 0 && xt < W)) return 0.0f;
-            const int py = yt % f, px = xt % f;
-            if (!((py == ph0 || py == ph1) && (px == ph0 || px == ph1))) return 0.0f;
-            return (two_lambda_df * r[(yt / f) * lw + (xt / f)]) * 0.25f;
+        auto gt_at = [&](int ly, int lx) -> float {
+            return (ly >= 0 && lx >= 0) ? (two_lambda_df * r[ly * lw + lx]) * 0.25f : 0.0f;
         };
-        auto rd_gr = [&](int yr, int xr) -> float {
-            if (!(yr >= 0 && yr < H && xr >= 0 && xr < W)) return 0.0f;
-            return asr_tf_sample(it, rd_gt, xr, yr);
-        };
-        g_df += asr_tf_sample(ir, rd_gr, X, Y);
+        const bool pure_translation = (it.a0 == 1.0f && it.a1 == 0.0f && it.b0 == 0.0f && it.b1 == 1.0f &&
+                                       it.c0 == 0.0f && it.c1 == 0.0f);
+        if (pure_translation) {
+            // rotation stage (generic affine), then the separable translate stage
+            float ix, iy;
+            asr_tf_map(ir, (float)X, (float)Y, ix, iy);
+            const float xf = floorf(ix), yf = floorf(iy);
+            const int x0 = asr_coord_to_int(xf), y0 = asr_coord_to_int(yf);
+            const SrAxisTap ax0 = sr_axis_tap<LOG2F>(x0, it.a2, W, f, ph0, ph1);
+            const SrAxisTap ax1 = sr_axis_tap<LOG2F>(x0 + 1, it.a2, W, f, ph0, ph1);
+            const SrAxisTap ay0 = sr_axis_tap<LOG2F>(y0, it.b2, H, f, ph0, ph1);
+            const SrAxisTap ay1 = sr_axis_tap<LOG2F>(y0 + 1, it.b2, H, f, ph0, ph1);
+            auto gr = [&](const SrAxisTap& ay, const SrAxisTap& ax) -> float {   // G_R at one integer position
+                if (!(ay.inb && ax.inb)) return 0.0f;
+                const float vyf = ax.wl * gt_at(ay.l0, ax.l0) + ax.wh * gt_at(ay.l0, ax.l1);
+                const float vyc = ax.wl * gt_at(ay.l1, ax.l0) + ax.wh * gt_at(ay.l1, ax.l1);
+                return ay.wl * vyf + ay.wh * vyc;
+            };
+            const float wxl = (xf + 1.0f) - ix, wxh = ix - xf;
+            const float vyf = wxl * gr(ay0, ax0) + wxh * gr(ay0, ax1);
+            const float vyc = wxl * gr(ay1, ax0) + wxh * gr(ay1, ax1);
+            g_df += ((yf + 1.0f) - iy) * vyf + (iy - yf) * vyc;
+        } else {
+            // generic projective inverse transforms (never produced by the reference's translate)
+            auto rd_gt = [&](int yt, int xt) -> float {
+                return gt_at(sr_gt_index<LOG2F>(yt, H, f, ph0, ph1), sr_gt_index<LOG2F>(xt, W, f, ph0, ph1));
+            };
+            auto rd_gr = [&](int yr, int xr) -> float {
+                if (!(yr >= 0 && yr < H && xr >= 0 && xr < W)) return 0.0f;
+                return asr_tf_sample(it, rd_gt, xr, yr);
+            };
+            g_df += asr_tf_sample(ir, rd_gr, X, Y);
+        }
     }
 
     // priors (superresolution.py:81-98): TV (forward differences, last row/col 0), L2, L1
@@ -148,6 +205,18 @@ __global__ __launch_bounds__(256) void sr_backward_adam_kernel(
         denom = sqrtf(vv) + adam.eps;
     }
     x_new[o] = xc - (mm * alpha) / denom;
+}
+
+typedef void (*SrBwdKernel)(const float*, float*, const float*, const float*, const float*, float*, float*, float*,
+                            const float*, float*, SrDims, float, float, float, float, AdamArgs);
+
+SrBwdKernel sr_backward_kernel_for(int f) {
+    switch (f) {
+        case 2: return sr_backward_adam_kernel<1>;
+        case 4: return sr_backward_adam_kernel<2>;
+        case 8: return sr_backward_adam_kernel<3>;
+        default: return sr_backward_adam_kernel<0>;   // any other even factor: integer division
+    }
 }
 
 // ---- loss terms (reporting only): out[b] = {df, tv, l2, l1} in float64 -------------------------
@@ -285,7 +354,7 @@ extern "C" int asr_sr_backward_adam_f32(const float* x, float* x_new, const floa
     int rc = check_dims("asr_sr_backward_adam_f32", batch, n, H, W, h, w, &d);
     if (rc != ASR_OK) return rc;
     AdamArgs a{one_minus_beta1, one_minus_beta2, epsilon, amsgrad};
-    hipLaunchKernelGGL(sr_backward_adam_kernel, hr_grid(d), kBlock, 0, asr_stream(stream), x, x_new, resid, inv_rot_tf,
+    hipLaunchKernelGGL(sr_backward_kernel_for(d.f), hr_grid(d), kBlock, 0, asr_stream(stream), x, x_new, resid, inv_rot_tf,
                        inv_trans_tf, m, v, vhat, alphas, grad_out, d, 2.0f * lambda_df, lambda_tv, 2.0f * lambda_l2,
                        lambda_l1, a);
     ASR_LAUNCH_CHECK();
@@ -340,6 +409,7 @@ extern "C" int asr_sr_solve_f32(float* x, const float* y, const float* rot_tf, c
     float* cur = x;
     float* nxt = x_alt;
     AdamArgs a{one_minus_beta1, one_minus_beta2, epsilon, amsgrad};
+    const SrBwdKernel bwd_kernel = sr_backward_kernel_for(d.f);
     for (int it = 0; it < num_iter; ++it) {
         hipLaunchKernelGGL(sr_forward_residual_kernel, lr_grid(d), kBlock, 0, s, cur, y, rot_tf, trans_tf, resid, d);
         ASR_LAUNCH_CHECK();
@@ -347,7 +417,7 @@ extern "C" int asr_sr_solve_f32(float* x, const float* y, const float* rot_tf, c
             rc = asr_sr_loss_terms_f64(cur, resid, last_loss_terms, batch, n, H, W, h, w, stream);
             if (rc != ASR_OK) return rc;
         }
-        hipLaunchKernelGGL(sr_backward_adam_kernel, hr_grid(d), kBlock, 0, s, cur, nxt, resid, inv_rot_tf, inv_trans_tf,
+        hipLaunchKernelGGL(bwd_kernel, hr_grid(d), kBlock, 0, s, cur, nxt, resid, inv_rot_tf, inv_trans_tf,
                            m, v, vhat, alphas + (size_t)it * batch, (float*)nullptr, d, 2.0f * lambda_df, lambda_tv,
                            2.0f * lambda_l2, lambda_l1, a);
         ASR_LAUNCH_CHECK();

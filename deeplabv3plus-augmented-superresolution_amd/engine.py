@@ -130,8 +130,8 @@ class DeeplabEngine:
         def release(buf):
             pool.put(buf.t)
 
-        def add(name, args, kind, flops=0, nbytes=0):
-            steps.append((name, tuple(args), kind, float(flops), float(nbytes)))
+        def add(name, args, kind, flops=0, nbytes=0, label=""):
+            steps.append((name, tuple(args), kind, float(flops), float(nbytes), label))
 
         def pw(x, name, out=None, out_off=0, ldy=None, relu=False, res=None, sub=1):
             p = self.p[name]
@@ -146,7 +146,8 @@ class DeeplabEngine:
                  res.ptr if res is not None else None, out.ptr + 4 * out_off, m, p["k"], p["n"], c, ldy,
                  res.shape[-1] if res is not None else 0, int(relu), sub, h if sub > 1 else 0, w if sub > 1 else 0),
                 "pw", 2.0 * m * p["k"] * p["n"],
-                4.0 * (m * p["k"] + m * p["n"] * (2 if res is not None else 1) + p["k"] * p["n"]))
+                4.0 * (m * p["k"] + m * p["n"] * (2 if res is not None else 1) + p["k"] * p["n"]),
+                label=f"{name} M={m} K={p['k']} N={p['n']}")
             return out
 
         def dw(x, name, stride, rate, pre_relu, post_relu):
@@ -159,7 +160,8 @@ class DeeplabEngine:
             add("asr_dwconv3x3_nhwc_f32",
                 (x.ptr, p["w"].data_ptr(), p["b"].data_ptr(), out.ptr, b, h, w, c, stride, rate, pad, pad, ho, wo, c, c,
                  int(pre_relu), int(post_relu), 0),
-                "dw", 18.0 * b * ho * wo * c, 4.0 * (b * h * w * c + b * ho * wo * c + 10 * c))
+                "dw", 18.0 * b * ho * wo * c, 4.0 * (b * h * w * c + b * ho * wo * c + 10 * c),
+                label=f"{name} {h}x{w}x{c} s{stride} r{rate}")
             return out
 
         def sepconv(x, prefix, stride=1, rate=1, depth_act=False, **pw_kw):
@@ -267,13 +269,13 @@ class DeeplabEngine:
         lib = _lib.load()
         s = _lib.stream_ptr()
         if profile is None:
-            for name, args, _kind, _fl, _by in plan["steps"]:
+            for name, args, _kind, _fl, _by, _lb in plan["steps"]:
                 rc = getattr(lib, name)(*args, s)
                 if rc != 0:
                     _lib.check(rc, name)
         else:
             evs = []
-            for name, args, kind, fl, by in plan["steps"]:
+            for name, args, kind, fl, by, label in plan["steps"]:
                 e0 = torch.cuda.Event(enable_timing=True)
                 e1 = torch.cuda.Event(enable_timing=True)
                 e0.record()
@@ -281,11 +283,14 @@ class DeeplabEngine:
                 e1.record()
                 if rc != 0:
                     _lib.check(rc, name)
-                evs.append((kind, e0, e1, fl, by))
+                evs.append((kind, e0, e1, fl, by, label))
             torch.cuda.synchronize()
-            for kind, e0, e1, fl, by in evs:
+            detail = profile.setdefault("_detail", [])
+            for kind, e0, e1, fl, by, label in evs:
                 acc = profile.setdefault(kind, [0.0, 0.0, 0.0, 0])
-                acc[0] += e0.elapsed_time(e1)
+                ms = e0.elapsed_time(e1)
+                detail.append((kind, label, ms, fl, by))
+                acc[0] += ms
                 acc[1] += fl
                 acc[2] += by
                 acc[3] += 1
@@ -294,7 +299,7 @@ class DeeplabEngine:
     def flops_per_copy(self, H, Wd):
         plan = self.plan(1, H, Wd)
         out = {}
-        for _n, _a, kind, fl, by in plan["steps"]:
+        for _n, _a, kind, fl, by, _lb in plan["steps"]:
             acc = out.setdefault(kind, [0.0, 0.0])
             acc[0] += fl
             acc[1] += by

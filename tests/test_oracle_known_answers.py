@@ -203,4 +203,4 @@ def test_oracle_model_runs_and_param_inventory():
     assert out.shape == (1, 16, 16, 21) and st["entry"].shape == (1, 4, 4, 728) and st["aspp"].shape == (1, 4, 4, 256)
     assert np.isfinite(out).all() and 0.05 < out.std() < 5
     n_conv = sum(1 for k, *_ in W.layer_inventory() if k in ("conv", "dw"))
-    assert n_conv == 2 + 20 * 6 + 4 + 2 + 6 + 2 + 4 + 1                 # 141 conv-type layers incl. shortcuts
+    assert n_conv == 2 + 21 * 6 + 4 + 9 + 5 + 1 == 147                  # 147 conv layers
