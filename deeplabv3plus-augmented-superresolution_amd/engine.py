@@ -16,6 +16,8 @@ launch functions allocate nothing and never synchronise).
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import torch
 
@@ -25,12 +27,15 @@ f32 = torch.float32
 
 
 class _Buf:
-    __slots__ = ("t", "shape", "last_use")
+    """NHWC activation: logical shape (b,h,w,c) stored with a pixel stride ``ld`` >= c that is a
+    multiple of 32 floats, so every pixel row starts on a 128-byte line (728 -> 736, 304 -> 320):
+    the GEMM's 128-byte A-row pieces and epilogue stores then map to whole cache lines."""
+    __slots__ = ("t", "shape", "ld")
 
-    def __init__(self, t, shape):
+    def __init__(self, t, shape, ld):
         self.t = t
         self.shape = shape
-        self.last_use = -1
+        self.ld = ld
 
     @property
     def ptr(self):
@@ -44,13 +49,20 @@ class _Pool:
         self.device = device
         self.free = {}
         self.total_bytes = 0
+        self.owned = []          # every tensor ever handed out: the plan stores raw pointers, so the pool
+                                 # (kept alive by the plan) must own the memory for the plan's lifetime
 
     def get(self, numel):
         lst = self.free.get(numel)
         if lst:
             return lst.pop()
         self.total_bytes += 4 * numel
-        return torch.empty(numel, dtype=f32, device=self.device)
+        if os.environ.get("ASR_POISON"):            # debugging aid: fill fresh buffers with a sentinel value
+            t = torch.full((numel,), float(os.environ["ASR_POISON"]), dtype=f32, device=self.device)
+        else:
+            t = torch.empty(numel, dtype=f32, device=self.device)
+        self.owned.append(t)
+        return t
 
     def put(self, t):
         self.free.setdefault(t.numel(), []).append(t)
@@ -123,31 +135,36 @@ class DeeplabEngine:
         steps = []          # (name, args, kind, flops, bytes)
         live = []           # buffers to release after a given step index
 
-        def new(shape):
-            n = int(np.prod(shape))
-            return _Buf(pool.get(n), tuple(shape))
+        def new(shape, pad=True):
+            c = shape[-1]
+            ld = -(-c // 32) * 32 if (pad and c >= 32) else c
+            n = int(np.prod(shape[:-1])) * ld
+            return _Buf(pool.get(n), tuple(shape), ld)
 
         def release(buf):
             pool.put(buf.t)
 
-        def add(name, args, kind, flops=0, nbytes=0, label=""):
-            steps.append((name, tuple(args), kind, float(flops), float(nbytes), label))
+        outs = []           # output buffer of every step (debug capture)
 
-        def pw(x, name, out=None, out_off=0, ldy=None, relu=False, res=None, sub=1):
+        def add(name, args, kind, flops=0, nbytes=0, label="", out=None):
+            steps.append((name, tuple(args), kind, float(flops), float(nbytes), label))
+            outs.append(out)
+
+        def pw(x, name, out=None, out_off=0, relu=False, res=None, sub=1, pad_out=True):
             p = self.p[name]
             b, h, w, c = x.shape
             ho, wo = (-(-h // sub), -(-w // sub)) if sub > 1 else (h, w)
             if out is None:
-                out = new((b, ho, wo, p["n"]))
-                ldy = p["n"]
+                out = new((b, ho, wo, p["n"]), pad=pad_out)
+            ldy = out.ld
             m = b * ho * wo
             add("asr_pwconv_mfma_f32",
                 (x.ptr, p["w"].data_ptr(), p["b"].data_ptr() if p["b"] is not None else None,
-                 res.ptr if res is not None else None, out.ptr + 4 * out_off, m, p["k"], p["n"], c, ldy,
-                 res.shape[-1] if res is not None else 0, int(relu), sub, h if sub > 1 else 0, w if sub > 1 else 0),
+                 res.ptr if res is not None else None, out.ptr + 4 * out_off, m, p["k"], p["n"], x.ld, ldy,
+                 res.ld if res is not None else 0, int(relu), sub, h if sub > 1 else 0, w if sub > 1 else 0),
                 "pw", 2.0 * m * p["k"] * p["n"],
                 4.0 * (m * p["k"] + m * p["n"] * (2 if res is not None else 1) + p["k"] * p["n"]),
-                label=f"{name} M={m} K={p['k']} N={p['n']}")
+                label=f"{name} M={m} K={p['k']} N={p['n']}", out=out)
             return out
 
         def dw(x, name, stride, rate, pre_relu, post_relu):
@@ -158,10 +175,10 @@ class DeeplabEngine:
                                                  (w + 2 * pad - (2 * rate + 1)) // stride + 1)
             out = new((b, ho, wo, c))
             add("asr_dwconv3x3_nhwc_f32",
-                (x.ptr, p["w"].data_ptr(), p["b"].data_ptr(), out.ptr, b, h, w, c, stride, rate, pad, pad, ho, wo, c, c,
-                 int(pre_relu), int(post_relu), 0),
+                (x.ptr, p["w"].data_ptr(), p["b"].data_ptr(), out.ptr, b, h, w, c, stride, rate, pad, pad, ho, wo, x.ld,
+                 out.ld, int(pre_relu), int(post_relu), 0),
                 "dw", 18.0 * b * ho * wo * c, 4.0 * (b * h * w * c + b * ho * wo * c + 10 * c),
-                label=f"{name} {h}x{w}x{c} s{stride} r{rate}")
+                label=f"{name} {h}x{w}x{c} s{stride} r{rate}", out=out)
             return out
 
         def sepconv(x, prefix, stride=1, rate=1, depth_act=False, **pw_kw):
@@ -189,7 +206,7 @@ class DeeplabEngine:
             return (r3, r2) if return_skip else r3
 
         # ---- entry flow (model.py:149-170) ----
-        x_in = new((B, H, Wd, 3))
+        x_in = new((B, H, Wd, 3), pad=False)
         h1, pt = _same_pad(H, 3, 2)
         w1, pl = _same_pad(Wd, 3, 2)
         a1 = new((B, h1, w1, 32))
@@ -215,17 +232,18 @@ class DeeplabEngine:
         # ---- ASPP (model.py:192-233) ----
         b, fh, fw, fc = x.shape
         cat = new((b, fh, fw, 1280))
-        pooled = new((b, 1, 1, fc))
-        add("asr_gap_f32", (x.ptr, pooled.ptr, b, fh * fw, fc, fc), "misc", b * fh * fw * fc, 4.0 * b * fh * fw * fc)
+        pooled = new((b, 1, 1, fc), pad=False)
+        add("asr_gap_f32", (x.ptr, pooled.ptr, b, fh * fw, fc, x.ld), "misc", b * fh * fw * fc, 4.0 * b * fh * fw * fc,
+            label="gap", out=pooled)
         pp = pw(pooled, "image_pooling", relu=True)
-        add("asr_resize_bilinear_f32", (pp.ptr, cat.ptr, b, 1, 1, 256, fh, fw, 256, 1280), "misc", 0,
+        add("asr_resize_bilinear_f32", (pp.ptr, cat.ptr, b, 1, 1, 256, fh, fw, pp.ld, cat.ld), "misc", 0,
             4.0 * b * fh * fw * 256)
         release(pooled)
         release(pp)
-        pw(x, "aspp0", out=cat, out_off=256, ldy=1280, relu=True)
+        pw(x, "aspp0", out=cat, out_off=256, relu=True)
         for i, rate in enumerate((6, 12, 18)):
             t = dw(x, f"aspp{i + 1}_depthwise", 1, rate, pre_relu=False, post_relu=True)
-            pw(t, f"aspp{i + 1}_pointwise", out=cat, out_off=512 + 256 * i, ldy=1280, relu=True)
+            pw(t, f"aspp{i + 1}_pointwise", out=cat, out_off=512 + 256 * i, relu=True)
             release(t)
         release(x)
         x = pw(cat, "concat_projection", relu=True)
@@ -233,18 +251,18 @@ class DeeplabEngine:
         # ---- decoder (model.py:235-259) ----
         sb, sh, sw, sc_ = skip.shape
         cat2 = new((sb, sh, sw, 304))
-        add("asr_resize_bilinear_f32", (x.ptr, cat2.ptr, b, fh, fw, 256, sh, sw, 256, 304), "misc", 0,
+        add("asr_resize_bilinear_f32", (x.ptr, cat2.ptr, b, fh, fw, 256, sh, sw, x.ld, cat2.ld), "misc", 0,
             4.0 * sb * sh * sw * 256)
         release(x)
-        pw(skip, "feature_projection0", out=cat2, out_off=256, ldy=304, relu=True)
+        pw(skip, "feature_projection0", out=cat2, out_off=256, relu=True)
         release(skip)
         x = sepconv(cat2, "decoder_conv0", 1, 1, True)
         release(cat2)
         y = sepconv(x, "decoder_conv1", 1, 1, True)
         release(x)
-        logits = pw(y, self.logits_name)
+        logits = pw(y, self.logits_name, pad_out=False)
         release(y)
-        plan = dict(steps=steps, x_in=x_in, logits=logits, pool_bytes=pool.total_bytes,
+        plan = dict(steps=steps, outs=outs, pool=pool, x_in=x_in, logits=logits, pool_bytes=pool.total_bytes,
                     out_shape=(B, sh, sw, self.classes))
         return plan
 
@@ -257,6 +275,21 @@ class DeeplabEngine:
         return self._plans[key]
 
     # -- execution --------------------------------------------------------------------------------
+    def forward_capture(self, x_dev):
+        """Debug: run the plan and return [(label, output tensor copy [rows, ld])] for every labelled step."""
+        B, H, Wd, _ = x_dev.shape
+        plan = self.plan(B, H, Wd)
+        plan["x_in"].t.copy_(x_dev.reshape(-1))
+        lib = _lib.load()
+        s = _lib.stream_ptr()
+        cap = []
+        for (name, args, _k, _f, _b, label), out in zip(plan["steps"], plan["outs"]):
+            _lib.check(getattr(lib, name)(*args, s), name)
+            if out is not None:
+                torch.cuda.synchronize()
+                cap.append((label, out.t.view(B, -1).clone()))
+        return cap
+
     def forward(self, x_dev, profile=None):
         """x_dev: [B,H,W,3] float32 device tensor -> logits [B,H/4,W/4,classes] (a view of plan
         memory: consume or clone it before the next forward of the same shape).

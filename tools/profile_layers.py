@@ -40,6 +40,15 @@ def main():
         g[0] += m; g[1] += f; g[2] += b
     for k, (m, f, b) in agg.items():
         print(f"  {k:5s} {m:8.2f} ms  {f / m / 1e9 if m else 0:8.1f} TF/s  {b / m / 1e6 if m else 0:8.1f} GB/s")
+    shapes = {}
+    for k, l, m, f, b in best:
+        if k in ("pw", "dw"):
+            key = k + " " + " ".join(l.split()[1:])
+            g = shapes.setdefault(key, [0, 0.0, 0.0, 0.0])
+            g[0] += 1; g[1] += m; g[2] += f; g[3] += b
+    print("-- by shape (count, total ms, TF/s, GB/s) --")
+    for key, (c, m, f, b) in sorted(shapes.items(), key=lambda kv: -kv[1][1]):
+        print(f"{key:48s} x{c:3d} {m:8.3f} ms {f / m / 1e9:8.1f} TF/s {b / m / 1e6:8.1f} GB/s")
     for k, l, m, f, b in best[:a.top]:
         print(f"{k:5s} {l:70s} {m * 1e3:9.1f} us {f / m / 1e9:8.1f} TF/s {b / m / 1e6:8.1f} GB/s")
 
