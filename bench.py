@@ -113,7 +113,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=64)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch-size", type=int, default=int(os.environ.get("ASR_BATCH", "50")))
+    ap.add_argument("--batch-size", type=int, default=int(os.environ.get("ASR_BATCH", "100")))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()

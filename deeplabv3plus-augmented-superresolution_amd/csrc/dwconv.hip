@@ -2,17 +2,24 @@
 // weights/bias and the ReLUs on either side fused (gfx950).
 //
 // Reference: model.py:463-508 (_SepConv_BN): [ZeroPadding2D if stride != 1] -> [ReLU if not
-// depth_activation] -> DepthwiseConv2D(3x3, stride, dilation) -> BN -> [ReLU if depth_activation].
+// depth_activation] -> DepthwiseConv2D(3x3, stride, dilation) -> BN -> [ReLU if depth_activation];
+// model.py:212-221 for the three ASPP branches (rates 6/12/18 on the same input).
 //
 // HBM-bound (2.1 flop/byte).  Channels are the fastest axis, so a lane owns 4 consecutive
 // channels (one 16-byte access) and neighbouring lanes neighbouring channels: every global
-// access of a wave covers whole 256-byte pixel rows.
-//  * dw_tiled_kernel (stride 1, rate 1 or 2 -- 90 % of the depthwise bytes): a 64-channel x
-//    (8+2R)x(16+2R) input tile is staged once through LDS (pre-ReLU applied on the way in);
-//    each lane then reads its 9 taps with conflict-free ds_read_b128 and writes 8 output rows.
-//  * dw_direct_kernel: any stride / rate (stride-2 block ends, ASPP rates 6/12/18 whose halo
-//    exceeds the 32x32 map), taps straight from L1/L2.
+// access of a wave covers whole 256-byte pieces of pixel rows.  Four kernels:
+//  * dw_stream_kernel<R,S,ROWS> (default for rate <= 2, stride 1 or 2 -- 93 % of the depthwise
+//    bytes): register sliding window.  A thread owns (4 channels, one output column) and marches
+//    down a strip of output rows keeping the (2R+1) x 3 taps in registers; the next input rows are
+//    loaded before the current row's FMAs; no barrier, >= 4 waves per SIMD.
+//  * dw_tiled_kernel<R>: LDS-staged (8+2R)x(16+2R)x64-channel input tile per workgroup (measured
+//    3.5-4.0 TB/s against 3.8-4.9 TB/s for the streaming form; kept selectable, ASR_DW_VARIANT=2).
+//  * aspp_dw3_kernel: the three dilated ASPP depthwise convs fused -- a whole H x W x 32-channel
+//    plane (128 KB at 32x32) is staged in LDS once and all three rates are computed from it, so
+//    the input is read from HBM once instead of three times.
+//  * dw_direct_kernel: any stride / rate, taps straight from L1/L2 (fallback).
 #include "asr_common.h"
+#include <stdlib.h>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -34,6 +41,9 @@ __device__ __forceinline__ f32x4 relu4(f32x4 v) {
     return v;
 }
 
+// ---------------------------------------------------------------------------------------------
+// LDS-tiled, stride 1
+// ---------------------------------------------------------------------------------------------
 constexpr int TH = 8, TW = 16, CB = 64;
 
 template <int R>
@@ -88,6 +98,212 @@ __global__ __launch_bounds__(256) void dw_tiled_kernel(DwArgs p, int tiles_x) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// register sliding window (stride S, rate R)
+// ---------------------------------------------------------------------------------------------
+constexpr int SCOLS = 16;
+
+template <int R, int S, int SROWS>
+__global__ __launch_bounds__(256) void dw_stream_kernel(DwArgs p, int tiles_x) {
+    constexpr int WIN = 2 * R + 1;
+    const int tid = threadIdx.x;
+    const int c4 = tid & 15, col = tid >> 4;
+    const int tx = blockIdx.x % tiles_x, cbk = blockIdx.x / tiles_x;
+    const int ch = (cbk * 16 + c4) * 4;
+    const int ox = tx * SCOLS + col;
+    const int oy0 = blockIdx.y * SROWS;
+    const int b = blockIdx.z;
+    if (ch >= p.c || ox >= p.w_out) return;
+    const float* xin = p.x + (long long)b * p.h_in * p.w_in * p.ldx + ch;
+    float* yout = p.y + (long long)b * p.h_out * p.w_out * p.ldy + ch;
+    f32x4 wk[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) wk[t] = *reinterpret_cast<const f32x4*>(p.w + (long long)t * p.c + ch);
+    const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + ch);
+    const int ixl = ox * S - p.pad_left, ixc = ixl + R, ixr = ixl + 2 * R;
+    const bool vl = ixl >= 0 && ixl < p.w_in, vc = ixc >= 0 && ixc < p.w_in, vr = ixr >= 0 && ixr < p.w_in;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+
+    auto load_row = [&](int iy, f32x4& l, f32x4& c, f32x4& r) {
+        l = zero; c = zero; r = zero;
+        if (iy >= 0 && iy < p.h_in) {
+            const float* row = xin + (long long)iy * p.w_in * p.ldx;
+            if (vl) l = *reinterpret_cast<const f32x4*>(row + (long long)ixl * p.ldx);
+            if (vc) c = *reinterpret_cast<const f32x4*>(row + (long long)ixc * p.ldx);
+            if (vr) r = *reinterpret_cast<const f32x4*>(row + (long long)ixr * p.ldx);
+            if (p.pre_relu) { l = relu4(l); c = relu4(c); r = relu4(r); }
+        }
+    };
+
+    // window rows [base, base + WIN) with base = oy * S - pad_top; it advances by S rows per output row
+    f32x4 win[WIN][3], nxt[S][3];
+    const int base0 = oy0 * S - p.pad_top;
+#pragma unroll
+    for (int k = 0; k < WIN - S; ++k) load_row(base0 + k, win[S + k][0], win[S + k][1], win[S + k][2]);
+#pragma unroll
+    for (int j = 0; j < S; ++j) load_row(base0 + WIN - S + j, nxt[j][0], nxt[j][1], nxt[j][2]);
+    const int rows = min(SROWS, p.h_out - oy0);
+    for (int r = 0; r < rows; ++r) {
+#pragma unroll
+        for (int k = 0; k < WIN - S; ++k) { win[k][0] = win[k + S][0]; win[k][1] = win[k + S][1]; win[k][2] = win[k + S][2]; }
+#pragma unroll
+        for (int j = 0; j < S; ++j) { win[WIN - S + j][0] = nxt[j][0]; win[WIN - S + j][1] = nxt[j][1]; win[WIN - S + j][2] = nxt[j][2]; }
+        if (r + 1 < rows) {  // prefetch the S input rows the next output row adds
+#pragma unroll
+            for (int j = 0; j < S; ++j) load_row(base0 + r * S + WIN + j, nxt[j][0], nxt[j][1], nxt[j][2]);
+        }
+        f32x4 acc = bv;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) acc += win[ky * R][kx] * wk[ky * 3 + kx];
+        if (p.post_relu) acc = relu4(acc);
+        *reinterpret_cast<f32x4*>(yout + ((long long)(oy0 + r) * p.w_out + ox) * p.ldy) = acc;
+    }
+}
+
+// Stride-1 variant of the register window with a FLAT (pixel, channel-quad) lane mapping: thread t of
+// a workgroup owns the 16-byte piece (row, f0 + t) of the image row seen as one contiguous array of
+// W * ld / 4 pieces, so every wave access is 1 KB contiguous (pixel boundaries included) and the
+// left / right taps are the same piece shifted by -+R pixels = -+R * ld floats.  No partially
+// filled channel chunk (728 = 11.4 x 64), whole-DRAM-burst accesses.  Needs ldx == ldy.
+template <int R, int SROWS>
+__global__ __launch_bounds__(256) void dw_flat_kernel(DwArgs p, int pieces_per_row) {
+    constexpr int WIN = 2 * R + 1;
+    const int q = p.ldx >> 2;                                  // 16-byte pieces per pixel
+    const int piece = blockIdx.x * 256 + threadIdx.x;          // along the image row
+    const int oy0 = blockIdx.y * SROWS;
+    const int b = blockIdx.z;
+    if (piece >= pieces_per_row) return;
+    const int ox = piece / q, c4 = piece - ox * q;
+    const int ch = c4 * 4;
+    if (ch >= p.c) return;                                     // stride padding lanes
+    const float* xin = p.x + (long long)b * p.h_in * p.w_in * p.ldx + (long long)piece * 4;
+    float* yout = p.y + (long long)b * p.h_out * p.w_out * p.ldy + (long long)piece * 4;
+    f32x4 wk[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) wk[t] = *reinterpret_cast<const f32x4*>(p.w + (long long)t * p.c + ch);
+    const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + ch);
+    const int ixl = ox - p.pad_left, ixc = ixl + R, ixr = ixl + 2 * R;
+    const bool vl = ixl >= 0 && ixl < p.w_in, vc = ixc >= 0 && ixc < p.w_in, vr = ixr >= 0 && ixr < p.w_in;
+    const long long offl = (long long)(ixl - ox) * p.ldx, offc = (long long)(ixc - ox) * p.ldx, offr = (long long)(ixr - ox) * p.ldx;
+    const long long row_stride = (long long)p.w_in * p.ldx;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+
+    auto load_row = [&](int iy, f32x4& l, f32x4& c, f32x4& r) {
+        l = zero; c = zero; r = zero;
+        if (iy >= 0 && iy < p.h_in) {
+            const float* row = xin + iy * row_stride;
+            if (vl) l = *reinterpret_cast<const f32x4*>(row + offl);
+            if (vc) c = *reinterpret_cast<const f32x4*>(row + offc);
+            if (vr) r = *reinterpret_cast<const f32x4*>(row + offr);
+            if (p.pre_relu) { l = relu4(l); c = relu4(c); r = relu4(r); }
+        }
+    };
+
+    f32x4 win[WIN][3], nl, nc, nr;
+    const int base0 = oy0 - p.pad_top;
+#pragma unroll
+    for (int k = 0; k < WIN - 1; ++k) load_row(base0 + k, win[k + 1][0], win[k + 1][1], win[k + 1][2]);
+    load_row(base0 + WIN - 1, nl, nc, nr);
+    const int rows = min(SROWS, p.h_out - oy0);
+    const long long out_stride = (long long)p.w_out * p.ldy;
+    for (int r = 0; r < rows; ++r) {
+#pragma unroll
+        for (int k = 0; k < WIN - 1; ++k) { win[k][0] = win[k + 1][0]; win[k][1] = win[k + 1][1]; win[k][2] = win[k + 1][2]; }
+        win[WIN - 1][0] = nl; win[WIN - 1][1] = nc; win[WIN - 1][2] = nr;
+        if (r + 1 < rows) load_row(base0 + WIN + r, nl, nc, nr);
+        f32x4 acc = bv;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) acc += win[ky * R][kx] * wk[ky * 3 + kx];
+        if (p.post_relu) acc = relu4(acc);
+        *reinterpret_cast<f32x4*>(yout + (oy0 + r) * out_stride) = acc;
+    }
+}
+
+template <int R>
+void launch_flat(const DwArgs& p, hipStream_t s) {
+    static const int srows_env = getenv("ASR_DW_SROWS") ? atoi(getenv("ASR_DW_SROWS")) : 0;
+    const int pieces = p.w_out * (p.ldx >> 2);
+    const int srows = srows_env ? srows_env : (p.h_out <= 32 ? 16 : 32);
+    const dim3 grid((unsigned)asr_cdiv(pieces, 256), (unsigned)asr_cdiv(p.h_out, srows), p.batch);
+    if (srows == 8) hipLaunchKernelGGL((dw_flat_kernel<R, 8>), grid, dim3(256), 0, s, p, pieces);
+    else if (srows == 16) hipLaunchKernelGGL((dw_flat_kernel<R, 16>), grid, dim3(256), 0, s, p, pieces);
+    else hipLaunchKernelGGL((dw_flat_kernel<R, 32>), grid, dim3(256), 0, s, p, pieces);
+}
+
+// ---------------------------------------------------------------------------------------------
+// fused ASPP: three dilation rates from one LDS-resident plane
+// ---------------------------------------------------------------------------------------------
+constexpr int ACB = 32;       // channels per workgroup (128-byte pieces of a pixel row)
+constexpr int ATHREADS = 512;
+
+struct AsppArgs {
+    const float* x;
+    const float* w;     // [3 branches][3][3][C]
+    const float* bias;  // [3][C]
+    float* y[3];
+    int batch, h, w_, c;
+    int rate[3];
+    int ldx, ldy;
+    int pre_relu, post_relu;
+};
+
+__global__ __launch_bounds__(ATHREADS) void aspp_dw3_kernel(AsppArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float plane[];  // [h*w][ACB]
+    const int tid = threadIdx.x;
+    const int cb = blockIdx.x * ACB;
+    const int b = blockIdx.y;
+    const int hw = p.h * p.w_;
+    const float* xin = p.x + (long long)b * hw * p.ldx;
+    for (int idx = tid; idx < hw * (ACB / 4); idx += ATHREADS) {
+        const int c4 = idx & 7, pix = idx >> 3;
+        const int ch = cb + c4 * 4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (ch < p.c) {
+            v = *reinterpret_cast<const f32x4*>(xin + (long long)pix * p.ldx + ch);
+            if (p.pre_relu) v = relu4(v);
+        }
+        *reinterpret_cast<f32x4*>(plane + idx * 4) = v;
+    }
+    __syncthreads();
+    const int c4 = tid & 7, slot = tid >> 3;  // 64 pixel slots
+    const int ch = cb + c4 * 4;
+    if (ch >= p.c) return;
+#pragma unroll 1
+    for (int br = 0; br < 3; ++br) {
+        const int rate = p.rate[br];
+        const float* wb = p.w + (long long)br * 9 * p.c + ch;
+        f32x4 wk[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) wk[t] = *reinterpret_cast<const f32x4*>(wb + (long long)t * p.c);
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + (long long)br * p.c + ch);
+        float* yout = p.y[br] + (long long)b * hw * p.ldy + ch;
+        for (int pix = slot; pix < hw; pix += ATHREADS / 8) {
+            const int y = pix / p.w_, x = pix - y * p.w_;
+            f32x4 acc = bv;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const int iy = y + (ky - 1) * rate;
+                if (iy < 0 || iy >= p.h) continue;
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int ix = x + (kx - 1) * rate;
+                    if (ix < 0 || ix >= p.w_) continue;
+                    acc += *reinterpret_cast<const f32x4*>(plane + ((iy * p.w_ + ix) * (ACB / 4) + c4) * 4) * wk[ky * 3 + kx];
+                }
+            }
+            if (p.post_relu) acc = relu4(acc);
+            *reinterpret_cast<f32x4*>(yout + (long long)pix * p.ldy) = acc;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// direct (fallback)
+// ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void dw_direct_kernel(DwArgs p) {
     const int c4n = p.c >> 2;
     const long long total = (long long)p.batch * p.h_out * p.w_out * c4n;
@@ -118,11 +334,23 @@ __global__ __launch_bounds__(256) void dw_direct_kernel(DwArgs p) {
     }
 }
 
+template <int R, int S>
+void launch_stream(const DwArgs& p, hipStream_t s) {
+    static const int srows_env = getenv("ASR_DW_SROWS") ? atoi(getenv("ASR_DW_SROWS")) : 0;
+    const int tiles_x = (int)asr_cdiv(p.w_out, SCOLS), chunks = (int)asr_cdiv(p.c, 64);
+    const int srows = srows_env ? srows_env : (p.h_out <= 32 ? 16 : 32);
+    const dim3 grid(tiles_x * chunks, (unsigned)asr_cdiv(p.h_out, srows), p.batch);
+    if (srows == 8) hipLaunchKernelGGL((dw_stream_kernel<R, S, 8>), grid, dim3(256), 0, s, p, tiles_x);
+    else if (srows == 16) hipLaunchKernelGGL((dw_stream_kernel<R, S, 16>), grid, dim3(256), 0, s, p, tiles_x);
+    else hipLaunchKernelGGL((dw_stream_kernel<R, S, 32>), grid, dim3(256), 0, s, p, tiles_x);
+}
+
 }  // namespace
 
+// mode: 0 = auto, 1 = direct, 2 = streaming (register window), 3 = LDS-tiled, 4 = flat streaming
 extern "C" int asr_dwconv3x3_nhwc_f32(const float* x, const float* w, const float* bias, float* y, int batch, int h_in,
                                       int w_in, int c, int stride, int rate, int pad_top, int pad_left, int h_out,
-                                      int w_out, int ldx, int ldy, int pre_relu, int post_relu, int force_direct,
+                                      int w_out, int ldx, int ldy, int pre_relu, int post_relu, int mode,
                                       asr_stream_t stream) {
     ASR_REQUIRE(x && w && bias && y, "asr_dwconv3x3_nhwc_f32: null pointer");
     ASR_REQUIRE(batch > 0 && h_in > 0 && w_in > 0 && c > 0 && h_out > 0 && w_out > 0 && stride > 0 && rate > 0 &&
@@ -135,9 +363,27 @@ extern "C" int asr_dwconv3x3_nhwc_f32(const float* x, const float* w, const floa
     ASR_UNSUPPORTED((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(w) |
                      reinterpret_cast<uintptr_t>(bias)) & 15,
                     "asr_dwconv3x3_nhwc_f32: pointers must be 16-byte aligned");
+    ASR_REQUIRE(mode >= 0 && mode <= 4, "asr_dwconv3x3_nhwc_f32: mode must be 0..4");
     DwArgs p{x, w, bias, y, batch, h_in, w_in, c, h_out, w_out, stride, rate, pad_top, pad_left, pre_relu, post_relu, ldx, ldy};
     hipStream_t s = asr_stream(stream);
-    if (!force_direct && stride == 1 && (rate == 1 || rate == 2) && batch <= 65535) {
+    static const int variant = getenv("ASR_DW_VARIANT") ? atoi(getenv("ASR_DW_VARIANT")) : 0;
+    const bool grid_ok = batch <= 65535;
+    const bool can_stream = grid_ok && ((stride == 1 && (rate == 1 || rate == 2)) || (stride == 2 && rate == 1));
+    const bool can_tile = grid_ok && stride == 1 && (rate == 1 || rate == 2);
+    const bool can_flat = can_tile && ldx == ldy && h_in == h_out && w_in == w_out;
+    // measured (profiles/): chunked streaming >= flat >= LDS-tiled on every layer of the net
+    if (mode == 0) mode = (variant == 2 && can_tile) ? 3 : ((variant == 4 && can_flat) ? 4 : (can_stream ? 2 : 1));
+    if (mode == 4) {
+        ASR_UNSUPPORTED(!can_flat, "asr_dwconv3x3_nhwc_f32: flat streaming kernel needs stride 1, rate 1|2, ldx == ldy, same-size output");
+        if (rate == 1) launch_flat<1>(p, s);
+        else launch_flat<2>(p, s);
+    } else if (mode == 2) {
+        ASR_UNSUPPORTED(!can_stream, "asr_dwconv3x3_nhwc_f32: streaming kernel needs (stride 1, rate 1|2) or (stride 2, rate 1)");
+        if (stride == 1 && rate == 1) launch_stream<1, 1>(p, s);
+        else if (stride == 1) launch_stream<2, 1>(p, s);
+        else launch_stream<1, 2>(p, s);
+    } else if (mode == 3) {
+        ASR_UNSUPPORTED(!can_tile, "asr_dwconv3x3_nhwc_f32: tiled kernel needs stride 1 and rate 1 or 2");
         const int tiles_x = (int)asr_cdiv(w_out, TW), tiles_y = (int)asr_cdiv(h_out, TH);
         const dim3 grid(tiles_x * tiles_y, (unsigned)asr_cdiv(c, CB), batch);
         if (rate == 1) hipLaunchKernelGGL(dw_tiled_kernel<1>, grid, dim3(256), 0, s, p, tiles_x);
@@ -147,6 +393,33 @@ extern "C" int asr_dwconv3x3_nhwc_f32(const float* x, const float* w, const floa
         const long long g = asr_cdiv(total, 256);
         hipLaunchKernelGGL(dw_direct_kernel, dim3((unsigned)(g < 8192 ? g : 8192)), dim3(256), 0, s, p);
     }
+    ASR_LAUNCH_CHECK();
+    return ASR_OK;
+}
+
+extern "C" int asr_aspp_dwconv3_nhwc_f32(const float* x, const float* w3, const float* bias3, float* y0, float* y1,
+                                         float* y2, int batch, int h, int w, int c, int rate0, int rate1, int rate2,
+                                         int ldx, int ldy, int pre_relu, int post_relu, asr_stream_t stream) {
+    ASR_REQUIRE(x && w3 && bias3 && y0 && y1 && y2, "asr_aspp_dwconv3_nhwc_f32: null pointer");
+    ASR_REQUIRE(batch > 0 && batch <= 65535 && h > 0 && w > 0 && c > 0 && rate0 > 0 && rate1 > 0 && rate2 > 0 && ldx >= c && ldy >= c,
+                "asr_aspp_dwconv3_nhwc_f32: bad geometry");
+    ASR_UNSUPPORTED((c & 3) || (ldx & 3) || (ldy & 3), "asr_aspp_dwconv3_nhwc_f32: c, ldx, ldy must be multiples of 4");
+    ASR_UNSUPPORTED((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y0) | reinterpret_cast<uintptr_t>(y1) |
+                     reinterpret_cast<uintptr_t>(y2) | reinterpret_cast<uintptr_t>(w3) | reinterpret_cast<uintptr_t>(bias3)) & 15,
+                    "asr_aspp_dwconv3_nhwc_f32: pointers must be 16-byte aligned");
+    const size_t lds = sizeof(float) * (size_t)h * w * ACB;
+    ASR_UNSUPPORTED(lds > 160 * 1024, "asr_aspp_dwconv3_nhwc_f32: %dx%d plane x %d channels (%zu B) exceeds the 160 KB LDS; "
+                    "use asr_dwconv3x3_nhwc_f32 per branch", h, w, ACB, lds);
+    static bool attr_set = false;
+    if (!attr_set) {
+        ASR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(aspp_dw3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    AsppArgs p{};
+    p.x = x; p.w = w3; p.bias = bias3; p.y[0] = y0; p.y[1] = y1; p.y[2] = y2;
+    p.batch = batch; p.h = h; p.w_ = w; p.c = c; p.rate[0] = rate0; p.rate[1] = rate1; p.rate[2] = rate2;
+    p.ldx = ldx; p.ldy = ldy; p.pre_relu = pre_relu; p.post_relu = post_relu;
+    hipLaunchKernelGGL(aspp_dw3_kernel, dim3((unsigned)asr_cdiv(c, ACB), batch), dim3(ATHREADS), lds, asr_stream(stream), p);
     ASR_LAUNCH_CHECK();
     return ASR_OK;
 }

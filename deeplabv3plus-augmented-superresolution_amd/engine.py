@@ -121,6 +121,9 @@ class DeeplabEngine:
         self._put_conv("aspp0", "aspp0_BN", e5)
         for i in (1, 2, 3):
             self._put_sep(f"aspp{i}", e3)
+        # branch-major stack of the three folded ASPP depthwise kernels for the fused kernel
+        self.p["aspp_dw3"] = dict(w=torch.stack([self.p[f"aspp{i}_depthwise"]["w"] for i in (1, 2, 3)]).contiguous(),
+                                  b=torch.stack([self.p[f"aspp{i}_depthwise"]["b"] for i in (1, 2, 3)]).contiguous())
         self._put_conv("concat_projection", "concat_projection_BN", e5)
         self._put_conv("feature_projection0", "feature_projection0_BN", e5)
         self._put_sep("decoder_conv0", e5)
@@ -241,10 +244,25 @@ class DeeplabEngine:
         release(pooled)
         release(pp)
         pw(x, "aspp0", out=cat, out_off=256, relu=True)
-        for i, rate in enumerate((6, 12, 18)):
-            t = dw(x, f"aspp{i + 1}_depthwise", 1, rate, pre_relu=False, post_relu=True)
-            pw(t, f"aspp{i + 1}_pointwise", out=cat, out_off=512 + 256 * i, relu=True)
-            release(t)
+        rates = (6, 12, 18)
+        if fh * fw * 128 <= 160 * 1024 and not os.environ.get("ASR_NO_FUSED_ASPP"):
+            # the three dilated depthwise convs read the same input: one fused launch stages each
+            # 32-channel plane in LDS once (input read from HBM 1x instead of 3x)
+            ts = [new((b, fh, fw, fc)) for _ in rates]
+            p3 = self.p["aspp_dw3"]
+            add("asr_aspp_dwconv3_nhwc_f32",
+                (x.ptr, p3["w"].data_ptr(), p3["b"].data_ptr(), ts[0].ptr, ts[1].ptr, ts[2].ptr, b, fh, fw, fc,
+                 rates[0], rates[1], rates[2], x.ld, ts[0].ld, 0, 1),
+                "dw", 3 * 18.0 * b * fh * fw * fc, 3 * 4.0 * 2 * b * fh * fw * fc,
+                label=f"aspp_dw3 {fh}x{fw}x{fc} r6/12/18 fused", out=ts[0])
+            for i, t in enumerate(ts):
+                pw(t, f"aspp{i + 1}_pointwise", out=cat, out_off=512 + 256 * i, relu=True)
+                release(t)
+        else:
+            for i, rate in enumerate(rates):
+                t = dw(x, f"aspp{i + 1}_depthwise", 1, rate, pre_relu=False, post_relu=True)
+                pw(t, f"aspp{i + 1}_pointwise", out=cat, out_off=512 + 256 * i, relu=True)
+                release(t)
         release(x)
         x = pw(cat, "concat_projection", relu=True)
         release(cat)

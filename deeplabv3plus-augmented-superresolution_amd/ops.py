@@ -279,8 +279,18 @@ def conv3x3_direct(x, w_hwio, bias, stride, pad_top, pad_left, out_hw, relu=Fals
     return y
 
 
+def aspp_dwconv3(x, w3, bias3, rates=(6, 12, 18), pre_relu=False, post_relu=True):
+    """Fused three-rate ASPP depthwise: x [B,H,W,C], w3 [3,3,3,C], bias3 [3,C] -> three [B,H,W,C]."""
+    b, h, w, c = x.shape
+    outs = [torch.empty((b, h, w, c), dtype=f32, device=x.device) for _ in range(3)]
+    call("asr_aspp_dwconv3_nhwc_f32", ptr(x), ptr(w3), ptr(bias3), ptr(outs[0]), ptr(outs[1]), ptr(outs[2]), b, h, w, c,
+         int(rates[0]), int(rates[1]), int(rates[2]), c, c, int(pre_relu), int(post_relu), stream_ptr())
+    return outs
+
+
 def dwconv3x3(x, w_33c, bias, stride=1, rate=1, pad_top=None, pad_left=None, out_hw=None, pre_relu=False,
-              post_relu=False, force_direct=False, out=None, ldy=None):
+              post_relu=False, force_direct=0, out=None, ldy=None):
+    """force_direct is the kernel mode: 0 auto, 1 direct, 2 streaming register window, 3 LDS-tiled."""
     b, h, w, c = x.shape
     if pad_top is None:
         pad_top = pad_left = rate            # stride-1 'same'

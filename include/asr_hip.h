@@ -183,10 +183,17 @@ int asr_conv3x3_direct_f32(const float* x, const float* w, const float* bias, fl
 
 /* DepthwiseConv2D 3x3 (+ ZeroPadding2D, folded BN, ReLU before and/or after): the depthwise half
  * of _SepConv_BN, model.py:478-495.  w [3,3,c] with the BN scale folded, bias [c].
- * force_direct != 0 selects the untiled kernel (testing). */
+ * mode: 0 = auto, 1 = direct, 2 = register-window streaming, 3 = LDS-tiled, 4 = flat streaming (testing / A-B runs). */
 int asr_dwconv3x3_nhwc_f32(const float* x, const float* w, const float* bias, float* y, int batch, int h_in,
                            int w_in, int c, int stride, int rate, int pad_top, int pad_left, int h_out, int w_out,
-                           int ldx, int ldy, int pre_relu, int post_relu, int force_direct, asr_stream_t stream);
+                           int ldx, int ldy, int pre_relu, int post_relu, int mode, asr_stream_t stream);
+
+/* The three dilated depthwise convs of the ASPP (aspp1/2/3_depthwise + BN + ReLU, model.py:212-221)
+ * fused: the input plane is staged in LDS once and read by all three rates.  w3 [3,3,3,c] (branch
+ * major), bias3 [3,c]; stride 1, 'same' padding; h*w*128 bytes must fit the 160 KB LDS. */
+int asr_aspp_dwconv3_nhwc_f32(const float* x, const float* w3, const float* bias3, float* y0, float* y1, float* y2,
+                              int batch, int h, int w, int c, int rate0, int rate1, int rate2, int ldx, int ldy,
+                              int pre_relu, int post_relu, asr_stream_t stream);
 
 /* GlobalAveragePooling2D(keepdims=True): y[b, :c] = mean over hw pixels (model.py:196-197). */
 int asr_gap_f32(const float* x, float* y, int batch, int hw, int c, int ldx, asr_stream_t stream);

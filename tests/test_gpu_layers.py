@@ -122,15 +122,24 @@ def _dw_ref(x, k, bias, stride, rate, pad, pre, post):
 
 
 @pytest.mark.parametrize("h,w_,c,stride,rate,pre,post,direct", [
-    (32, 32, 728, 1, 1, True, False, False),     # middle flow, C not a multiple of 64
-    (40, 24, 128, 1, 1, True, False, False),     # ragged tiles
-    (32, 32, 1536, 1, 2, False, True, False),    # exit block 2
-    (32, 32, 256, 1, 1, False, True, True),      # direct kernel, same result
-    (64, 64, 128, 2, 1, True, False, False),     # stride-2 block end (explicit pad 1,1)
-    (32, 32, 2048, 1, 6, False, True, False),    # ASPP
-    (32, 32, 512, 1, 12, False, True, False),
-    (32, 32, 512, 1, 18, False, True, False),
-    (9, 7, 8, 1, 1, False, False, False),        # tiny
+    # last field = kernel mode: 0 auto (streaming where possible), 1 direct, 2 streaming, 3 LDS-tiled
+    (32, 32, 728, 1, 1, True, False, 3),         # middle flow, C not a multiple of 64, LDS-tiled
+    (40, 24, 128, 1, 1, True, False, 3),         # ragged tiles
+    (32, 32, 1536, 1, 2, False, True, 3),        # exit block 2, LDS-tiled
+    (32, 32, 256, 1, 1, False, True, 1),         # direct kernel, same result
+    (64, 64, 128, 2, 1, True, False, 1),         # stride-2 block end (explicit pad 1,1), direct
+    (64, 64, 128, 2, 1, True, False, 0),         # stride-2, streaming (auto)
+    (70, 50, 256, 2, 1, True, True, 2),          # stride-2 streaming, odd sizes, several strips
+    (32, 32, 2048, 1, 6, False, True, 0),        # ASPP rates: direct fallback
+    (32, 32, 512, 1, 12, False, True, 0),
+    (32, 32, 512, 1, 18, False, True, 0),
+    (9, 7, 8, 1, 1, False, False, 0),            # tiny
+    (32, 32, 728, 1, 1, True, False, 2),         # streaming (register window) kernel
+    (70, 40, 128, 1, 1, True, True, 2),          # streaming: several row strips, ragged columns
+    (32, 32, 1536, 1, 2, False, True, 2),        # streaming, rate 2
+    (32, 32, 728, 1, 1, True, False, 4),         # flat streaming (default for stride 1)
+    (70, 40, 132, 1, 1, True, True, 4),          # flat: ragged rows, several strips, pieces not a multiple of 256
+    (32, 32, 1536, 1, 2, False, True, 4),        # flat, rate 2
 ])
 def test_dwconv_matches_conv2d(dev, h, w_, c, stride, rate, pre, post, direct):
     from asr_amd import ops
@@ -148,9 +157,23 @@ def test_dwconv_matches_conv2d(dev, h, w_, c, stride, rate, pre, post, direct):
     ref = _dw_ref(x, k, bias, stride, rate, pad, pre, post)
     got = ops.dwconv3x3(ops.to_device(x), ops.to_device(k), ops.to_device(bias), stride=stride, rate=rate,
                         pad_top=pad[0], pad_left=pad[2], out_hw=out_hw, pre_relu=pre, post_relu=post,
-                        force_direct=direct).cpu().numpy()
+                        force_direct=int(direct)).cpu().numpy()
     assert got.shape == ref.shape
     np.testing.assert_allclose(got, ref, rtol=1e-5, atol=2e-5)
+
+
+def test_aspp_fused_three_rates(dev):
+    """aspp1-3 depthwise (rates 6/12/18, BN folded, ReLU after) from one LDS-resident plane."""
+    from asr_amd import ops
+    rng = np.random.default_rng(15)
+    for (h, w_, c) in ((32, 32, 256), (16, 24, 72)):
+        x = _rand(rng, 2, h, w_, c)
+        k3 = _rand(rng, 3, 3, 3, c, scale=0.3)
+        b3 = _rand(rng, 3, c)
+        outs = ops.aspp_dwconv3(ops.to_device(x), ops.to_device(k3), ops.to_device(b3), rates=(6, 12, 18))
+        for i, r in enumerate((6, 12, 18)):
+            ref = _dw_ref(x, k3[i], b3[i], 1, r, (r, r, r, r), False, True)
+            np.testing.assert_allclose(outs[i].cpu().numpy(), ref, rtol=1e-5, atol=2e-5)
 
 
 def test_gap_and_resize(dev):
