@@ -218,10 +218,19 @@ def main():
         torch.cuda.synchronize()
         ms, flops, nbytes, launches = prof["pw"]
         achieved = flops / (ms * 1e-3) / 1e12
+        pmc = {}
+        pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if os.path.exists(pmc_path):       # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/pmc_traffic.sh), gfx950-corrected
+            with open(pmc_path) as fh:
+                pmc = json.load(fh)
         out["roofline"] = {
             "kernel": "pw_gemm_kernel (asr_pwconv_mfma_f32, v_mfma_f32_32x32x2_f32)",
             "bound": "mfma", "achieved": round(achieved, 3), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+            "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4),
+            "traffic": pmc.get("pw_gemm_kernel<2, 2, 2, 2, false, false>", {}).get("hbm_bytes_per_launch"),
+            "traffic_note": "HBM bytes per launch of the 128x128-tile kernel (97 % of the GEMM launches) from profiles/r01_pmc_traffic.json "
+                            "(separate FETCH_SIZE / WRITE_SIZE passes, FETCH doubled per the gfx950 rule)",
+            "algorithmic_bytes_per_launch": round(nbytes / launches),
             "launches": launches, "avg_launch_ms": round(ms / launches, 4),
             "algorithmic_gflop_per_launch": round(flops / launches / 1e9, 3),
             "note": "HIP events around every launch of one extra profiled step after the timed region",

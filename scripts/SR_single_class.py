@@ -1,0 +1,85 @@
+#!/usr/bin/env python3
+"""Batch consumer: interchange files -> ASR / max-SR / mean-SR -> IoUs per image -> means.  Counterpart of
+the reference's SR_single_class.py (same hyper-parameters and IoU record); images sharded over the GPUs of
+the node, one all-gather of the per-image IoU records at the end (asr_amd.distributed)."""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+IMG_SIZE = (512, 512)
+FEATURE_SIZE = (128, 128)
+HYPER = dict(lambda_df=1, lambda_tv=0.3, lambda_L2=0.7, lambda_L1=0.0, num_iter=300, optimizer="adam",
+             learning_rate=1e-3, amsgrad=True, lr_scheduler=True, decay_steps=60, decay_rate=0.3)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--data", required=True, help="folder of interchange files written by generate_augmented_copies.py")
+    ap.add_argument("--gt", required=True, help="folder of ground-truth label PNGs named <filename>.png")
+    ap.add_argument("--standard", default=None, help="folder of standard-output PNGs (optional)")
+    ap.add_argument("--num_aug", type=int, default=10)
+    ap.add_argument("--num_samples", type=int, default=500)
+    ap.add_argument("--class_id", type=int, default=8)
+    ap.add_argument("--th_factor", type=float, default=0.65)
+    ap.add_argument("--out", default=os.path.join(ROOT, "data", "superres_root", "superres_output"))
+    args = ap.parse_args()
+
+    import torch
+    from asr_amd import distributed as D
+    from asr_amd.utils import load_image, compute_IoU
+    from asr_amd.superresolution_scripts.optimizer import Optimizer
+    from asr_amd.superresolution_scripts.superresolution import Superresolution
+    from asr_amd.superresolution_scripts.superres_utils import list_precomputed_data_paths, load_SR_data, compute_SR
+
+    rank, world, local_rank = D.init_from_env()
+    torch.cuda.set_device(local_rank)
+    optimizer_obj = Optimizer(optimizer=HYPER["optimizer"], learning_rate=HYPER["learning_rate"], amsgrad=HYPER["amsgrad"],
+                              lr_scheduler=HYPER["lr_scheduler"], decay_steps=HYPER["decay_steps"],
+                              decay_rate=HYPER["decay_rate"])
+    sr = Superresolution(lambda_df=HYPER["lambda_df"], lambda_tv=HYPER["lambda_tv"], lambda_L2=HYPER["lambda_L2"],
+                         lambda_L1=HYPER["lambda_L1"], num_iter=HYPER["num_iter"], num_aug=args.num_aug,
+                         optimizer=optimizer_obj, feature_size=FEATURE_SIZE)
+    paths = list_precomputed_data_paths(args.data, sort=False)[:args.num_samples]
+    mine = D.shard_indices(len(paths), rank, world)
+    records = []
+    for g in mine:
+        try:
+            class_masks, max_masks, angles, shifts, filename = load_SR_data(paths[g], num_aug=args.num_aug)
+        except Exception:
+            print(f"File: {paths[g]} is invalid, skipping...")
+            records.append([np.nan] * 6)
+            continue
+        mode_solves = 2 if max_masks is not None else 1
+        optimizer_obj.optimizer.iterations = g * HYPER["num_iter"] * mode_solves     # the reference's persistent counter
+        true_mask = load_image(os.path.join(args.gt, f"{filename}.png"), image_size=IMG_SIZE, normalize=False,
+                               is_png=True, resize_method="nearest")
+        mm = max_masks if max_masks is not None else []
+        out = {t: compute_SR(sr, class_masks, angles, shifts, filename, max_masks=mm, SR_type=t, class_id=args.class_id,
+                             dest_folder=args.out, th_factor=args.th_factor) for t in ("aug", "max", "mean")}
+        std = [np.nan, np.nan]
+        if args.standard:
+            sm = load_image(os.path.join(args.standard, f"{filename}.png"), image_size=IMG_SIZE, normalize=False,
+                            is_png=True, resize_method="nearest")
+            std = [compute_IoU(true_mask, sm, img_size=IMG_SIZE, class_id=args.class_id),
+                   compute_IoU(true_mask, sm, img_size=IMG_SIZE, class_id=args.class_id, include_bg=True)]
+        records.append(std + [compute_IoU(true_mask, out["aug"], img_size=IMG_SIZE, class_id=args.class_id),
+                              compute_IoU(true_mask, out["aug"], img_size=IMG_SIZE, class_id=args.class_id, include_bg=True),
+                              compute_IoU(true_mask, out["max"], img_size=IMG_SIZE, class_id=args.class_id),
+                              compute_IoU(true_mask, out["mean"], img_size=IMG_SIZE, class_id=args.class_id)])
+    table = D.all_gather_iou(mine, records, len(paths))
+    if rank == 0:
+        m = D.mean_ious(table)
+        print(f"Avg. Standard IoUs (No bg): {m['standard_single']},  Avg. Augmented SR IoUs (No bg): {m['aug_single']}")
+        print(f"Avg. Standard IoUs (with bg): {m['standard_bg']},  Avg. Augmented SR IoUs (with bg): {m['aug_bg']}")
+        print(f"Avg. Max SR IoUs: {m['max']}, Avg. Mean SR IoUs: {m['mean']}")
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

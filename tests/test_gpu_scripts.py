@@ -1,0 +1,44 @@
+"""The two-stage command-line flow (generate_augmented_copies -> SR_single_class) and the single-image
+demo (test_SR), run as child processes on the GPU like a user of the reference would."""
+import os
+import shutil
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(args, cwd):
+    r = subprocess.run([sys.executable] + args, cwd=cwd, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    return r.stdout
+
+
+def test_two_stage_scripts(dev, golden_dir, tmp_path):
+    imgs = tmp_path / "JPEGImages"
+    gts = tmp_path / "gt"
+    imgs.mkdir()
+    gts.mkdir()
+    shutil.copy(os.path.join(golden_dir, "test_cat.jpg"), imgs / "7.jpg")          # numeric names like VOC ids
+    shutil.copy(os.path.join(golden_dir, "test_cat_gt.png"), gts / "7.png")
+    out_root = tmp_path / "copies"
+    _run([os.path.join(ROOT, "scripts", "generate_augmented_copies.py"), "--images", str(imgs), "--num_aug", "4",
+          "--mode", "argmax", "--angle_max", "0.15", "--shift_max", "80", "--class_id", "8", "--out_root", str(out_root)],
+         str(tmp_path))
+    data_dir = out_root / "xception_argmax_8_4"
+    assert (data_dir / "7.npz").exists()
+    out = _run([os.path.join(ROOT, "scripts", "SR_single_class.py"), "--data", str(data_dir), "--gt", str(gts),
+                "--num_aug", "4", "--class_id", "8", "--out", str(tmp_path / "sr_out")], str(tmp_path))
+    assert "Avg. Max SR IoUs" in out and "Avg. Augmented SR IoUs" in out
+
+
+def test_single_image_demo(dev, tmp_path):
+    out = _run([os.path.join(ROOT, "scripts", "test_SR.py"), "--num-aug", "4", "--num-iter", "20", "--out",
+                str(tmp_path / "SR_output")], str(tmp_path))
+    assert "Aug. SR (argmax OPM) IoU" in out
+    for t in ("aug", "max", "mean"):
+        assert (tmp_path / "SR_output" / f"{t}_SR" / f"test_cat_{t}_SR.png").exists()
