@@ -42,6 +42,7 @@ SR_ITERS = 50
 TH_FACTOR = 0.2
 F32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: FP32 matrix peak (spec), dense
 HBM_PEAK_GBS = 8000.0
+F16_MFMA_PEAK_TFLOPS = 2500.0     # dense f16/bf16 MFMA peak (spec)
 
 
 def synth_image(rng, size=IMG, box=8):
@@ -114,6 +115,9 @@ def main():
     ap.add_argument("--steps", type=int, default=64)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch-size", type=int, default=int(os.environ.get("ASR_BATCH", "100")))
+    ap.add_argument("--precision", choices=["f16x3", "f32"], default=os.environ.get("ASR_PRECISION", "f16x3"),
+                    help="pointwise GEMM arithmetic: f16x3 = split-f16 MFMA with f32 accumulation (f32-grade results), "
+                         "f32 = v_mfma_f32_32x32x2_f32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -138,7 +142,8 @@ def main():
     per_rank = K + Wm
     total_images = per_rank * world
     weights = W.make_synthetic_weights(1234, 21)
-    model = DeeplabModel(weights, (IMG, IMG, 3), 21, final_upsample=False, last_activation=None)
+    model = DeeplabModel(weights, (IMG, IMG, 3), 21, final_upsample=False, last_activation=None,
+                         precision=args.precision)
     opt = Optimizer("adam", 1e-3, amsgrad=True, lr_scheduler=True, decay_steps=60, decay_rate=0.3)
     sr = Superresolution(1.0, 0.3, 0.7, 0.0, num_iter=SR_ITERS, num_aug=NUM_AUG, optimizer=opt,
                          feature_size=(FEAT, FEAT), output_size=(IMG, IMG))
@@ -196,12 +201,14 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32",
+        "dtype": ("f32 (pointwise GEMMs: operands split into f16 hi+lo, hi*hi+hi*lo+lo*hi on f16 MFMA, f32 accumulate)"
+                  if args.precision == "f16x3" else "f32"),
         "data": "synthetic",
         "config": {
             "workload": ("BASELINE configs[1]: synthetic 512x512 images, num_aug=100, angle+-0.15 shift+-80, argmax OPM "
                          "class 8, ASR 50 AMSGrad iters + max-SR + mean-SR + threshold + 6 IoUs; step = 1 image = 100 copies; "
-                         "DeepLabV3+ Xception-65 OS16 f32, seeded synthetic weights"),
+                         "DeepLabV3+ Xception-65 OS16, f32 activations/accumulation, seeded synthetic weights"),
+            "precision": args.precision,
             "images_per_gpu": K, "num_aug": NUM_AUG, "sr_iters": SR_ITERS, "forward_batch": args.batch_size,
             "parallelism": f"images sharded over {world} GPU(s), one all-gather of IoU records",
         },
@@ -216,30 +223,46 @@ def main():
         prof = {}
         step(Wm, profile=prof)
         torch.cuda.synchronize()
-        ms, flops, nbytes, launches = prof["pw"]
-        achieved = flops / (ms * 1e-3) / 1e12
         pmc = {}
         pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
         if os.path.exists(pmc_path):       # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/pmc_traffic.sh), gfx950-corrected
             with open(pmc_path) as fh:
                 pmc = json.load(fh)
-        out["roofline"] = {
-            "kernel": "pw_gemm_kernel (asr_pwconv_mfma_f32, v_mfma_f32_32x32x2_f32)",
-            "bound": "mfma", "achieved": round(achieved, 3), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4),
-            "traffic": pmc.get("pw_gemm_kernel<2, 2, 2, 2, false, false>", {}).get("hbm_bytes_per_launch"),
-            "traffic_note": "HBM bytes per launch of the 128x128-tile kernel (97 % of the GEMM launches) from profiles/r01_pmc_traffic.json "
-                            "(separate FETCH_SIZE / WRITE_SIZE passes, FETCH doubled per the gfx950 rule)",
-            "algorithmic_bytes_per_launch": round(nbytes / launches),
-            "launches": launches, "avg_launch_ms": round(ms / launches, 4),
-            "algorithmic_gflop_per_launch": round(flops / launches / 1e9, 3),
-            "note": "HIP events around every launch of one extra profiled step after the timed region",
-        }
+
+        def gemm_roofline(kind, kernel, pmc_key, peak, peak_note):
+            ms, flops, nbytes, launches = prof[kind]
+            achieved = flops / (ms * 1e-3) / 1e12
+            return {
+                "kernel": kernel, "bound": "mfma", "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s",
+                "frac": round(achieved / peak, 4), "peak_note": peak_note,
+                "traffic": pmc.get(pmc_key, {}).get("hbm_bytes_per_launch"),
+                "traffic_note": "HBM bytes per launch from profiles/r01_pmc_traffic.json (separate FETCH_SIZE / WRITE_SIZE "
+                                "passes, FETCH doubled per the gfx950 rule)",
+                "algorithmic_bytes_per_launch": round(nbytes / launches),
+                "launches": launches, "avg_launch_ms": round(ms / launches, 4),
+                "algorithmic_gflop_per_launch": round(flops / launches / 1e9, 3),
+                "note": "algorithmic 2*M*K*N flop of the launches / HIP-event time around every launch of one extra "
+                        "profiled step after the timed region",
+            }
+
+        if "pw16" in prof:
+            out["roofline"] = gemm_roofline(
+                "pw16", "pw_gemm_f16x3_kernel (asr_pwconv_mfma_f16x3, v_mfma_f32_32x32x16_f16 x3)", "pw_gemm_f16x3_kernel",
+                round(F16_MFMA_PEAK_TFLOPS / 3.0, 1),
+                "dense f16 MFMA peak 2500 TFLOP/s / 3 MFMA products per f32-grade product")
+            if "pw" in prof:
+                out["roofline_f32_mfma_layers"] = gemm_roofline(
+                    "pw", "pw_gemm_kernel (layers with <= 64 output channels)", "pw_gemm_kernel<2, 2, 2, 1, false, false>",
+                    F32_MFMA_PEAK_TFLOPS, "FP32 MFMA peak (spec)")
+        else:
+            out["roofline"] = gemm_roofline("pw", "pw_gemm_kernel (asr_pwconv_mfma_f32, v_mfma_f32_32x32x2_f32)",
+                                            "pw_gemm_kernel<2, 2, 2, 2, false, false>", F32_MFMA_PEAK_TFLOPS,
+                                            "FP32 MFMA peak 157.3 TFLOP/s (spec)")
         if "dw" in prof:
             dms, _dfl, dby, dl = prof["dw"]
             gbs = dby / (dms * 1e-3) / 1e9
             out["roofline_depthwise"] = {
-                "kernel": "dw_tiled_kernel / dw_direct_kernel (asr_dwconv3x3_nhwc_f32)", "bound": "hbm",
+                "kernel": "dw_stream_kernel / aspp_dw3_kernel (asr_dwconv3x3_nhwc_f32, asr_aspp_dwconv3_nhwc_f32)", "bound": "hbm",
                 "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
                 "traffic": None, "launches": dl, "avg_launch_ms": round(dms / dl, 4),
             }

@@ -57,6 +57,9 @@ SIGNATURES = {
     "asr_pwconv_packed_floats": (_sz, [_i, _i]),
     "asr_pwconv_pack_weights_f32": (_i, [_vp, _vp, _i, _i, _vp]),
     "asr_pwconv_mfma_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "asr_pwconv_packed_floats_f16x3": (_sz, [_i, _i]),
+    "asr_pwconv_pack_weights_f16x3": (_i, [_vp, _vp, _i, _i, _vp]),
+    "asr_pwconv_mfma_f16x3": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "asr_conv3x3_mfma_f32": (_i, [_vp, _vp, _vp, _vp] + [_i] * 13 + [_vp]),
     "asr_conv3x3_direct_f32": (_i, [_vp, _vp, _vp, _vp] + [_i] * 13 + [_vp]),
     "asr_dwconv3x3_nhwc_f32": (_i, [_vp, _vp, _vp, _vp] + [_i] * 15 + [_vp]),

@@ -36,7 +36,7 @@ struct PwArgs {
     const float* res;
     float* y;
     long long M;
-    int K, N, Npad;
+    int K, N, Npad, Kpad;
     int ldx, ldy, ldres;
     int relu;
     int tiles_n;
@@ -46,6 +46,65 @@ struct PwArgs {
     int h_in, w_in, h_out, w_out, stride, pad, dil;
     int debug;  // bit0: skip epilogue stores (timing experiments only)
 };
+
+// ---- epilogue shared by the f32 and the split-f16 kernels ------------------------------------------
+// C/D map of every 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
+// The accumulators hold columns on lanes; writing them straight out would cost 16 dword stores per
+// 32x32 tile, each touching two 128-byte row pieces.  Instead every wave transposes its
+// (32 x TN*32) half-tile through its own slice of the (now idle) staging LDS and stores whole
+// 16-byte pieces: 16 lanes cover one 256-byte row segment, 4x fewer store instructions.
+// The caller guarantees (barrier) that no wave still reads the staging tiles.
+template <int WM, int WN, int TM, int TN>
+__device__ __forceinline__ void pw_epilogue(const PwArgs& p, f32x16 (&acc)[TM][TN], float* smem, int tile_m, int tile_n,
+                                            int wave, int lane) {
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    constexpr int WCOLS = TN * 32;                 // columns of the wave's sub-tile
+    constexpr int LPR = WCOLS / 4;                 // lanes per row in the read-back
+    constexpr int RPI = 64 / LPR;                  // rows per wave-instruction
+    const int wm = wave / WN, wn = wave % WN;
+    const int l32 = lane & 31, hh = lane >> 5;
+    float* const stage = smem + wave * (32 * WCOLS);
+    const bool vec_ok = ((p.N & 3) == 0) && ((p.ldy & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.y) & 15) == 0) &&
+                        (!p.res || (((p.ldres & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.res) & 15) == 0)));
+    const int n_wave = tile_n * BN + wn * WCOLS;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n_wave + j * 32 + l32;
+            const float bv = (p.bias && n < p.N) ? p.bias[n] : 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                float v = acc[i][j][e] + bv;
+                if (p.relu) v = fmaxf(v, 0.f);
+                stage[((e & 3) + 8 * (e >> 2) + 4 * hh) * WCOLS + j * 32 + l32] = v;
+            }
+        }
+        const long long m_base = (long long)tile_m * BM + (wm * TM + i) * 32;
+        const int c4 = lane % LPR, r_in = lane / LPR;
+        const int n = n_wave + c4 * 4;
+#pragma unroll
+        for (int rr = 0; rr < 32; rr += RPI) {
+            const int r = rr + r_in;
+            const long long m = m_base + r;
+            f32x4 v = *reinterpret_cast<const f32x4*>(stage + r * WCOLS + c4 * 4);
+            if (m < p.M && n < p.N) {
+                if (vec_ok) {
+                    if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + m * p.ldres + n);
+                    *reinterpret_cast<f32x4*>(p.y + m * p.ldy + n) = v;
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (n + q < p.N) {
+                            float o = v[q];
+                            if (p.res) o += p.res[m * p.ldres + n + q];
+                            p.y[m * p.ldy + n + q] = o;
+                        }
+                }
+            }
+        }
+    }
+}
 
 template <int WM, int WN, int TM, int TN, bool CONV, bool DBUF>
 __global__ __launch_bounds__(256) void pw_gemm_kernel(PwArgs p) {
@@ -202,55 +261,173 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwArgs p) {
                 for (int e = 0; e < 16; ++e) asm volatile("" ::"v"(acc[i][j][e]));
         return;
     }
-    // The accumulators hold columns on lanes; writing them straight out would cost 16 dword stores per
-    // 32x32 tile, each touching two 128-byte row pieces.  Instead every wave transposes its
-    // (32 x TN*32) half-tile through its own slice of the (now idle) staging LDS and stores whole
-    // 16-byte pieces: 16 lanes cover one 256-byte row segment, 4x fewer store instructions.
-    constexpr int WCOLS = TN * 32;                 // columns of the wave's sub-tile
-    constexpr int LPR = WCOLS / 4;                 // lanes per row in the read-back
-    constexpr int RPI = 64 / LPR;                  // rows per wave-instruction
-    static_assert(WM * WN * 32 * WCOLS <= NBUF * (BM * BK + BK * BN), "epilogue staging does not fit the LDS");
-    float* const stage = smem + wave * (32 * WCOLS);
     if (!DBUF) __syncthreads();                    // all waves are done reading the last K-tile
-    const bool vec_ok = ((p.N & 3) == 0) && ((p.ldy & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.y) & 15) == 0) &&
-                        (!p.res || (((p.ldres & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.res) & 15) == 0)));
-    const int n_wave = tile_n * BN + wn * WCOLS;
+    static_assert(WM * WN * 32 * TN * 32 <= NBUF * (BM * BK + BK * BN), "epilogue staging does not fit the LDS");
+    pw_epilogue<WM, WN, TM, TN>(p, acc, smem, tile_m, tile_n, wave, lane);
+}
+
+// =================================================================================================
+// Split-f16 ("f16x3") variant: x = hi + lo with hi = f16(x), lo = f16(x - hi) carries 22 mantissa
+// bits, and x*w ~= hi_x*hi_w + hi_x*lo_w + lo_x*hi_w (the dropped lo*lo term is < 2^-22 relative)
+// runs on v_mfma_f32_32x32x16_f16 with f32 accumulation: 3 MFMAs at 16x the f32-MFMA rate = 5.3x
+// less matrix-pipe time for f32-grade results (max error ~1e-6 relative to sum |a||w|, the size of
+// f32 summation-order noise).  Activations stay f32 in HBM; the split happens on the way into LDS.
+// 128x128 tile, BK = 32, 4 waves, same epilogue.  LDS: A_hi/A_lo [128][32] halfs (16-byte slots
+// XOR-swizzled by (row >> 2) & 3), B_hi/B_lo [4 octets][128][8] halfs from the pre-split packed
+// weights ([K/8][Npad][8] per plane) -- 32 KB, single buffer, 2 barriers per K-tile.
+// =================================================================================================
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void split_f16x8(const f32x4& a, const f32x4& b, f16x8& hi, f16x8& lo) {
+    const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
+    for (int j = 0; j < 8; ++j) {
+        const _Float16 h = (_Float16)v[j];
+        hi[j] = h;
+        lo[j] = (_Float16)(v[j] - (float)h);
+    }
+}
+
+__global__ __launch_bounds__(256) void pw_gemm_f16x3_kernel(PwArgs p) {
+    constexpr int WM = 2, WN = 2, TM = 2, TN = 2, BM = 128, BN = 128;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    _Float16* const sAh = reinterpret_cast<_Float16*>(smem);   // 128 rows x 32 k
+    _Float16* const sAl = sAh + BM * BK;
+    _Float16* const sBh = sAl + BM * BK;                         // 4 octets x 128 cols x 8
+    _Float16* const sBl = sBh + BK * BN;
+
+    const int nwg = gridDim.x, orig = blockIdx.x;
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
+    const int lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+    const int tile_m = lid / p.tiles_n, tile_n = lid % p.tiles_n;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int l32 = lane & 31, hh = lane >> 5;
+
+    // A staging: thread owns octet (tid & 3) of rows (tid >> 2) and 64 + (tid >> 2)
+    const int a_oct = tid & 3;
+    const float* a_base[2];
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int n = n_wave + j * 32 + l32;
-            const float bv = (p.bias && n < p.N) ? p.bias[n] : 0.f;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                float v = acc[i][j][e] + bv;
-                if (p.relu) v = fmaxf(v, 0.f);
-                stage[((e & 3) + 8 * (e >> 2) + 4 * hh) * WCOLS + j * 32 + l32] = v;
+    for (int i = 0; i < 2; ++i) {
+        const int row = (tid >> 2) + 64 * i;
+        const long long m = (long long)tile_m * BM + row;
+        a_base[i] = nullptr;
+        if (m < p.M) {
+            if (p.h_out > 0) {
+                const int ox = (int)(m % p.w_out);
+                const long long t = m / p.w_out;
+                const int oy = (int)(t % p.h_out);
+                const long long b = t / p.h_out;
+                a_base[i] = p.x + ((b * p.h_in + (long long)oy * p.stride) * p.w_in + (long long)ox * p.stride) * p.ldx;
+            } else {
+                a_base[i] = p.x + m * p.ldx;
             }
         }
-        const long long m_base = (long long)tile_m * BM + (wm * TM + i) * 32;
-        const int c4 = lane % LPR, r_in = lane / LPR;
-        const int n = n_wave + c4 * 4;
+    }
+    const long long plane = (long long)p.Kpad * p.Npad;          // halfs per weight plane
+    const _Float16* const wh = reinterpret_cast<const _Float16*>(p.wp) + (long long)tile_n * BN * 8;
+    f32x4 ra[2][2];
+    f16x8 rbh[2], rbl[2];
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+    auto load_tile = [&](int kt) {
+        const int k0 = kt * BK;
 #pragma unroll
-        for (int rr = 0; rr < 32; rr += RPI) {
-            const int r = rr + r_in;
-            const long long m = m_base + r;
-            f32x4 v = *reinterpret_cast<const f32x4*>(stage + r * WCOLS + c4 * 4);
-            if (m < p.M && n < p.N) {
-                if (vec_ok) {
-                    if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + m * p.ldres + n);
-                    *reinterpret_cast<f32x4*>(p.y + m * p.ldy + n) = v;
-                } else {
+        for (int i = 0; i < 2; ++i) {
+            const int k = k0 + a_oct * 8;
+            ra[i][0] = (a_base[i] && k < p.K) ? *reinterpret_cast<const f32x4*>(a_base[i] + k) : zero4;
+            ra[i][1] = (a_base[i] && k + 4 < p.K) ? *reinterpret_cast<const f32x4*>(a_base[i] + k + 4) : zero4;
+        }
 #pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        if (n + q < p.N) {
-                            float o = v[q];
-                            if (p.res) o += p.res[m * p.ldres + n + q];
-                            p.y[m * p.ldy + n + q] = o;
-                        }
+        for (int i = 0; i < 2; ++i) {
+            const int slot = tid + 256 * i;
+            const int oct = slot >> 7, n = slot & 127;
+            const long long off = ((long long)(k0 / 8 + oct) * p.Npad + n) * 8;
+            rbh[i] = *reinterpret_cast<const f16x8*>(wh + off);
+            rbl[i] = *reinterpret_cast<const f16x8*>(wh + plane + off);
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = (tid >> 2) + 64 * i;
+            f16x8 hi, lo;
+            split_f16x8(ra[i][0], ra[i][1], hi, lo);
+            const int off = (row * 4 + (a_oct ^ ((row >> 2) & 3))) * 8;
+            *reinterpret_cast<f16x8*>(sAh + off) = hi;
+            *reinterpret_cast<f16x8*>(sAl + off) = lo;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int slot = tid + 256 * i;
+            *reinterpret_cast<f16x8*>(sBh + slot * 8) = rbh[i];
+            *reinterpret_cast<f16x8*>(sBl + slot * 8) = rbl[i];
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int KT = (p.K + BK - 1) / BK;
+    load_tile(0);
+    store_tile();
+    __syncthreads();
+    for (int kt = 0; kt < KT; ++kt) {
+        if (kt + 1 < KT) load_tile(kt + 1);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int oct = 2 * s + hh;
+            f16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int row = (wm * TM + i) * 32 + l32;
+                const int off = (row * 4 + (oct ^ ((row >> 2) & 3))) * 8;
+                ah[i] = *reinterpret_cast<const f16x8*>(sAh + off);
+                al[i] = *reinterpret_cast<const f16x8*>(sAl + off);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int col = (wn * TN + j) * 32 + l32;
+                bh[j] = *reinterpret_cast<const f16x8*>(sBh + (oct * BN + col) * 8);
+                bl[j] = *reinterpret_cast<const f16x8*>(sBl + (oct * BN + col) * 8);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
                 }
-            }
         }
+        if (kt + 1 < KT) {
+            __syncthreads();
+            store_tile();
+            __syncthreads();
+        }
+    }
+    __syncthreads();
+    pw_epilogue<WM, WN, TM, TN>(p, acc, smem, tile_m, tile_n, wave, lane);
+}
+
+// w [K][N] f32 -> two half planes [Kpad/8][Npad][8] (hi then lo), zero padded
+__global__ __launch_bounds__(256) void pack_weights_f16x3_kernel(const float* __restrict__ w, _Float16* __restrict__ wp, int K,
+                                                                 int N, int Kpad, int Npad) {
+    const long long total = (long long)Kpad * Npad;
+    for (long long o = (long long)blockIdx.x * 256 + threadIdx.x; o < total; o += (long long)gridDim.x * 256) {
+        const int kr = (int)(o & 7);
+        const long long t = o >> 3;
+        const int n = (int)(t % Npad);
+        const int k = (int)(t / Npad) * 8 + kr;
+        const float v = (k < K && n < N) ? w[(long long)k * N + n] : 0.f;
+        const _Float16 h = (_Float16)v;
+        wp[o] = h;
+        wp[total + o] = (_Float16)(v - (float)h);
     }
 }
 
@@ -377,4 +554,51 @@ extern "C" int asr_conv3x3_mfma_f32(const float* x, const float* w_packed, const
     a.taps = 9; a.cin = cin; a.h_in = h_in; a.w_in = w_in; a.h_out = h_out; a.w_out = w_out;
     a.stride = stride; a.pad = pad; a.dil = dil;
     return dispatch<true>(a, asr_stream(stream));
+}
+
+// ---- split-f16 entry points ---------------------------------------------------------------------------
+extern "C" size_t asr_pwconv_packed_floats_f16x3(int k, int n) {
+    if (k <= 0 || n <= 0) return 0;
+    return (size_t)round_up(k, BK) * (size_t)round_up(n, 128);   // two half planes = one float per (k, n)
+}
+
+extern "C" int asr_pwconv_pack_weights_f16x3(const float* w_kn, float* w_packed, int k, int n, asr_stream_t stream) {
+    ASR_REQUIRE(w_kn && w_packed, "asr_pwconv_pack_weights_f16x3: null pointer");
+    ASR_REQUIRE(k > 0 && n > 0, "asr_pwconv_pack_weights_f16x3: bad shape k=%d n=%d", k, n);
+    const int Kpad = round_up(k, BK), Npad = round_up(n, 128);
+    const long long total = (long long)Kpad * Npad;
+    const int grid = (int)(asr_cdiv(total, 256) < 4096 ? asr_cdiv(total, 256) : 4096);
+    hipLaunchKernelGGL(pack_weights_f16x3_kernel, dim3(grid), dim3(256), 0, asr_stream(stream), w_kn,
+                       reinterpret_cast<_Float16*>(w_packed), k, n, Kpad, Npad);
+    ASR_LAUNCH_CHECK();
+    return ASR_OK;
+}
+
+extern "C" int asr_pwconv_mfma_f16x3(const float* x, const float* w_packed, const float* bias, const float* residual, float* y,
+                                     int64_t m, int k, int n, int ldx, int ldy, int ldres, int relu, int sub_stride,
+                                     int h_in, int w_in, asr_stream_t stream) {
+    int rc = check_common("asr_pwconv_mfma_f16x3", x, w_packed, y, m, k, n, ldx, ldy, residual, ldres);
+    if (rc != ASR_OK) return rc;
+    ASR_REQUIRE(ldx >= k, "asr_pwconv_mfma_f16x3: ldx < k");
+    ASR_UNSUPPORTED(k & 3, "asr_pwconv_mfma_f16x3: k must be a multiple of 4 (got %d)", k);
+    PwArgs a{};
+    a.x = x; a.wp = w_packed; a.bias = bias; a.res = residual; a.y = y;
+    a.M = m; a.K = k; a.N = n; a.Npad = round_up(n, 128); a.Kpad = round_up(k, BK);
+    a.ldx = ldx; a.ldy = ldy; a.ldres = ldres; a.relu = relu;
+    a.taps = 1; a.cin = k; a.stride = 1; a.pad = 0; a.dil = 1;
+    if (sub_stride > 1) {
+        ASR_REQUIRE(h_in > 0 && w_in > 0, "asr_pwconv_mfma_f16x3: h_in/w_in required with sub_stride");
+        a.h_in = h_in; a.w_in = w_in; a.stride = sub_stride;
+        a.h_out = (h_in + sub_stride - 1) / sub_stride;
+        a.w_out = (w_in + sub_stride - 1) / sub_stride;
+        ASR_REQUIRE(m % ((long long)a.h_out * a.w_out) == 0, "asr_pwconv_mfma_f16x3: m is not a whole number of %dx%d maps",
+                    a.h_out, a.w_out);
+    }
+    a.tiles_n = (int)asr_cdiv(n, 128);
+    const long long nwg = asr_cdiv(m, 128) * a.tiles_n;
+    ASR_REQUIRE(nwg <= 0x7fffffffLL, "asr_pwconv_mfma_f16x3: grid too large");
+    const size_t lds = sizeof(float) * (128 * BK + BK * 128);
+    hipLaunchKernelGGL(pw_gemm_f16x3_kernel, dim3((unsigned)nwg), dim3(256), lds, asr_stream(stream), a);
+    ASR_LAUNCH_CHECK();
+    return ASR_OK;
 }

@@ -77,8 +77,14 @@ def _same_pad(in_size, k_eff, stride):
 class DeeplabEngine:
     """Folded / packed parameters on the device + per-(batch, H, W) launch plans."""
 
-    def __init__(self, weights: dict, classes=21, device=None):
+    def __init__(self, weights: dict, classes=21, device=None, precision=None):
+        """precision: 'f32' = v_mfma_f32_32x32x2_f32 everywhere (exact f32 fmaf chains);
+        'f16x3' = split-f16 MFMA (hi*hi + hi*lo + lo*hi, f32 accumulate; f32-grade results, ~2.4x faster)
+        for the pointwise GEMMs with more than 64 output channels.  Default: $ASR_PRECISION or 'f16x3'."""
         self.device = device or _lib.require_gpu()
+        self.precision = precision or os.environ.get("ASR_PRECISION", "f16x3")
+        if self.precision not in ("f32", "f16x3"):
+            raise ValueError(f"precision must be 'f32' or 'f16x3', got {self.precision!r}")
         self.classes = classes
         self.logits_name = "logits_semantic" if "logits_semantic/kernel" in weights else "custom_logits_semantic"
         self.p = {}
@@ -94,8 +100,10 @@ class DeeplabEngine:
                 (self._w[name + "/kernel"].reshape(-1, self._w[name + "/kernel"].shape[-1]).astype(np.float32),
                  self._w.get(name + "/bias")))
         kd = self._dev(k)
-        self.p[name] = dict(w=ops.pack_pw_weights(kd) if pack else kd, b=self._dev(b) if b is not None else None,
-                            k=k.shape[0], n=k.shape[1])
+        split = pack and self.precision == "f16x3" and k.shape[1] > 64 and name != "entry_flow_conv1_2"
+        wdev = (ops.pack_pw_weights_f16x3(kd) if split else ops.pack_pw_weights(kd)) if pack else kd
+        self.p[name] = dict(w=wdev, b=self._dev(b) if b is not None else None, k=k.shape[0], n=k.shape[1],
+                            fn="asr_pwconv_mfma_f16x3" if split else "asr_pwconv_mfma_f32")
 
     def _put_dw(self, name, bn, eps):
         k, b = W.fold_dw_bn(self._w, name, bn, eps)
@@ -161,11 +169,11 @@ class DeeplabEngine:
                 out = new((b, ho, wo, p["n"]), pad=pad_out)
             ldy = out.ld
             m = b * ho * wo
-            add("asr_pwconv_mfma_f32",
+            add(p.get("fn", "asr_pwconv_mfma_f32"),
                 (x.ptr, p["w"].data_ptr(), p["b"].data_ptr() if p["b"] is not None else None,
                  res.ptr if res is not None else None, out.ptr + 4 * out_off, m, p["k"], p["n"], x.ld, ldy,
                  res.ld if res is not None else 0, int(relu), sub, h if sub > 1 else 0, w if sub > 1 else 0),
-                "pw", 2.0 * m * p["k"] * p["n"],
+                "pw16" if p.get("fn", "").endswith("f16x3") else "pw", 2.0 * m * p["k"] * p["n"],
                 4.0 * (m * p["k"] + m * p["n"] * (2 if res is not None else 1) + p["k"] * p["n"]),
                 label=f"{name} M={m} K={p['k']} N={p['n']}", out=out)
             return out

@@ -18,7 +18,7 @@ from .engine import DeeplabEngine
 class DeeplabV3Plus:
     def __init__(self, weights='pascal_voc', input_tensor=None, input_shape=(512, 512, 3), classes=21, OS=16,
                  last_activation=None, load_weights=True, reshape_outputs=False, backbone="xception", alpha=1.,
-                 weights_path=None, synthetic_seed=1234):
+                 weights_path=None, synthetic_seed=1234, precision=None):
         # same argument checks / messages as model.py:20-30
         if not (weights in {'pascal_voc', None}):
             raise ValueError('The `weights` argument should be either '
@@ -46,6 +46,7 @@ class DeeplabV3Plus:
         self.OS = OS
         self.weights_path = weights_path
         self.synthetic_seed = synthetic_seed
+        self.precision = precision          # None -> $ASR_PRECISION or 'f32'; 'f16x3' = split-f16 MFMA GEMMs
 
     def build_model(self, only_DCNN_output=False, only_ASPP_output=False, first_upsample_size=(128, 128),
                     final_upsample=True, final_class_prediction=True):
@@ -58,20 +59,22 @@ class DeeplabV3Plus:
         else:
             # The pretrained .h5 is a network download (model.py:134-143): unavailable offline.
             params = W.make_synthetic_weights(self.synthetic_seed, self.classes)
-        return DeeplabModel(params, self.input_shape, self.classes, final_upsample, self.last_activation)
+        return DeeplabModel(params, self.input_shape, self.classes, final_upsample, self.last_activation,
+                            precision=self.precision)
 
 
 class DeeplabModel:
     """What ``build_model`` returns: only ``predict`` (and ``predict_device``) are used by callers
     (augmentation_utils.py:76)."""
 
-    def __init__(self, params, input_shape, classes, final_upsample, last_activation):
+    def __init__(self, params, input_shape, classes, final_upsample, last_activation, precision=None):
         self.input_shape = tuple(input_shape)
         self.classes = classes
         self.final_upsample = final_upsample
         self.last_activation = last_activation
         self.name = "DLV3Plus-xception-OS16"
-        self.engine = DeeplabEngine(params, classes)
+        self.engine = DeeplabEngine(params, classes, precision=precision)
+        self.precision = self.engine.precision
         self.device = self.engine.device
 
     def predict_device(self, x, batch_size=16, profile=None):

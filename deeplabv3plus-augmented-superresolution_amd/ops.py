@@ -245,9 +245,18 @@ def pack_pw_weights(w_kn):
     return out
 
 
+def pack_pw_weights_f16x3(w_kn):
+    k, n = w_kn.shape
+    lib = _lib.load()
+    out = torch.empty(lib.asr_pwconv_packed_floats_f16x3(k, n), dtype=f32, device=w_kn.device)
+    call("asr_pwconv_pack_weights_f16x3", ptr(w_kn), ptr(out), k, n, stream_ptr())
+    return out
+
+
 def pwconv(x, w_packed, bias, k, n, out=None, residual=None, relu=False, ldx=None, ldy=None, ldres=None, m=None,
-           sub_stride=1, h_in=0, w_in=0):
-    """Rows of x ([..., ldx] with the first k columns used) times packed W [k,n]."""
+           sub_stride=1, h_in=0, w_in=0, f16x3=False):
+    """Rows of x ([..., ldx] with the first k columns used) times packed W [k,n].  f16x3: w_packed comes from
+    pack_pw_weights_f16x3 and the split-f16 kernel is used."""
     ldx = ldx or x.shape[-1]
     m = m if m is not None else x.numel() // ldx
     if out is None:
@@ -255,7 +264,8 @@ def pwconv(x, w_packed, bias, k, n, out=None, residual=None, relu=False, ldx=Non
         ldy = n
     ldy = ldy or out.shape[-1]
     ldres = ldres or (residual.shape[-1] if residual is not None else 0)
-    call("asr_pwconv_mfma_f32", ptr(x), ptr(w_packed), ptr(bias, allow_none=True), ptr(residual, allow_none=True),
+    call("asr_pwconv_mfma_f16x3" if f16x3 else "asr_pwconv_mfma_f32", ptr(x), ptr(w_packed), ptr(bias, allow_none=True),
+         ptr(residual, allow_none=True),
          ptr(out), m, k, n, ldx, ldy, ldres, int(relu), sub_stride, h_in, w_in, stream_ptr())
     return out
 

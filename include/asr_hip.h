@@ -170,6 +170,17 @@ int asr_pwconv_mfma_f32(const float* x, const float* w_packed, const float* bias
                         int64_t m, int k, int n, int ldx, int ldy, int ldres, int relu, int sub_stride, int h_in,
                         int w_in, asr_stream_t stream);
 
+/* Split-f16 variant of asr_pwconv_mfma_f32 (same arguments, n > 64): every f32 operand is split into
+ * f16 hi + lo on the way into LDS and x*w is evaluated as hi*hi + hi*lo + lo*hi on
+ * v_mfma_f32_32x32x16_f16 with f32 accumulation -- f32-grade results (error ~1e-6 of sum |x||w|) at
+ * 3/16 of the FP32-MFMA matrix time.  Weights are packed by asr_pwconv_pack_weights_f16x3
+ * (asr_pwconv_packed_floats_f16x3 floats: two half planes [ceil32(k)/8][ceil128(n)][8]). */
+size_t asr_pwconv_packed_floats_f16x3(int k, int n);
+int asr_pwconv_pack_weights_f16x3(const float* w_kn, float* w_packed, int k, int n, asr_stream_t stream);
+int asr_pwconv_mfma_f16x3(const float* x, const float* w_packed, const float* bias, const float* residual, float* y,
+                          int64_t m, int k, int n, int ldx, int ldy, int ldres, int relu, int sub_stride, int h_in,
+                          int w_in, asr_stream_t stream);
+
 /* Conv2D 3x3 as implicit GEMM on FP32 MFMA (cin % 32 == 0): entry_flow_conv1_2, model.py:155-159. */
 int asr_conv3x3_mfma_f32(const float* x, const float* w_packed, const float* bias, float* y, int batch, int h_in,
                          int w_in, int cin, int cout, int stride, int pad, int dil, int h_out, int w_out, int ldx,

@@ -42,6 +42,39 @@ def test_pwconv_matches_reference(dev, m, k, n, relu, res):
     np.testing.assert_allclose(got, ref, rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("m,k,n,relu,res", [
+    (1000, 728, 728, False, True),
+    (384, 2048, 256, True, False),
+    (130, 64, 128, False, False),
+    (4, 2048, 256, True, False),
+    (512, 304, 256, True, False),
+])
+def test_pwconv_split_f16_is_f32_grade(dev, m, k, n, relu, res):
+    """hi/lo f16 split on v_mfma_f32_32x32x16_f16: error must stay at f32 summation-noise level
+    (<= 4e-6 of sum |x||w|), including operands spanning several orders of magnitude."""
+    from asr_amd import ops
+    rng = np.random.default_rng(m + k + n + 1)
+    x = _rand(rng, m, k) * np.exp(rng.uniform(-6, 3, (m, k))).astype(np.float32)   # wide dynamic range
+    w = _rand(rng, k, n, scale=1.0 / np.sqrt(k))
+    b = _rand(rng, n)
+    r = _rand(rng, m, n) if res else None
+    ref = x.astype(np.float64) @ w.astype(np.float64) + b
+    if relu:
+        ref = np.maximum(ref, 0)
+    if res:
+        ref = ref + r
+    bound = np.abs(x).astype(np.float64) @ np.abs(w).astype(np.float64) + np.abs(b)
+    wp = ops.pack_pw_weights_f16x3(ops.to_device(w))
+    got = ops.pwconv(ops.to_device(x), wp, ops.to_device(b), k, n, relu=relu,
+                     residual=ops.to_device(r) if res else None, f16x3=True).cpu().numpy()
+    err = np.abs(got - ref) / bound
+    assert err.max() <= 4e-6, err.max()
+    # the plain f32 MFMA kernel on the same data, for scale
+    got32 = ops.pwconv(ops.to_device(x), ops.pack_pw_weights(ops.to_device(w)), ops.to_device(b), k, n, relu=relu,
+                       residual=ops.to_device(r) if res else None).cpu().numpy()
+    assert (np.abs(got32 - ref) / bound).max() <= 4e-6
+
+
 def test_pwconv_asymmetric_identity(dev):
     """A = I with an asymmetric B catches a transposed C-write or a wrong k permutation exactly."""
     from asr_amd import ops

@@ -20,12 +20,15 @@ def synthetic():
     return W.make_synthetic_weights(seed=1234, classes=21)
 
 
-def test_engine_logits_match_oracle(dev, synthetic):
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+def test_engine_logits_match_oracle(dev, synthetic, precision):
+    """Both GEMM arithmetics: exact-f32 MFMA and the split-f16 MFMA (f32-grade by construction)."""
     from asr_amd.model import DeeplabModel
     rng = np.random.default_rng(21)
     x = rng.random((3, 64, 96, 3), dtype=np.float32)
     ref = OracleDeeplabV3Plus(synthetic).forward(x)
-    model = DeeplabModel(synthetic, (64, 96, 3), 21, final_upsample=False, last_activation=None)
+    model = DeeplabModel(synthetic, (64, 96, 3), 21, final_upsample=False, last_activation=None, precision=precision)
+    assert model.precision == precision
     got = model.predict(x, batch_size=2)                      # 2 + 1: exercises two plans
     assert got.shape == ref.shape == (3, 16, 24, 21)
     scale = np.abs(ref).max()

@@ -9,7 +9,8 @@ size = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 b = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 x = np.random.default_rng(0).random((b, size, size, 3), dtype=np.float32)
 ref = OracleDeeplabV3Plus(w).forward(x)
-m = DeeplabModel(w, (size, size, 3), 21, False, None)
+m = DeeplabModel(w, (size, size, 3), 21, False, None, precision=os.environ.get('ASR_PRECISION'))
+print('precision', m.precision)
 for rep in range(3):
     got = m.predict(x, batch_size=b)
     print(size, b, "rep", rep, "maxdiff", np.abs(got - ref).max(), "scale", np.abs(ref).max(), "argmax agree", (got.argmax(-1) == ref.argmax(-1)).mean(), flush=True)
