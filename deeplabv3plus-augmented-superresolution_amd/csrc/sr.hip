@@ -57,12 +57,17 @@ __global__ __launch_bounds__(256) void sr_forward_residual_kernel(
     const AsrTf8 tt = asr_load_tf(trans_tf + (int64_t)bn * 8);
     const int H = d.H, W = d.W;
 
+    // Branch-free taps: clamp the index, load unconditionally, select afterwards -- the 64 image taps of one
+    // residual element are then issued back to back instead of one exec-masked branch + wait each.
     auto rd_x = [&](int yy, int xx) -> float {
-        return (yy >= 0 && yy < H && xx >= 0 && xx < W) ? img[yy * W + xx] : 0.0f;
+        const bool ok = (yy >= 0) & (yy < H) & (xx >= 0) & (xx < W);
+        const float v = img[ok ? yy * W + xx : 0];
+        return ok ? v : 0.0f;
     };
     auto rd_rot = [&](int yr, int xr) -> float {
-        if (!(yr >= 0 && yr < H && xr >= 0 && xr < W)) return 0.0f;
-        return asr_tf_sample(tr, rd_x, xr, yr);
+        const bool ok = (yr >= 0) & (yr < H) & (xr >= 0) & (xr < W);
+        const float v = asr_tf_sample(tr, rd_x, xr, yr);
+        return ok ? v : 0.0f;
     };
     auto T = [&](int yt, int xt) -> float { return asr_tf_sample(tt, rd_rot, xt, yt); };
 
@@ -115,6 +120,14 @@ __device__ __forceinline__ SrAxisTap sr_axis_tap(int c, float shift, int size, i
     return a;
 }
 
+// Work split: a workgroup owns 64 HR pixels (32 x 2) and NSPLIT = 4 waves; wave g evaluates the copies
+// n = g, g + 4, ... for those pixels (the copy index is wave-uniform, so the transforms are scalar loads)
+// and parks each contribution in LDS as contrib[n][pixel]; after one barrier wave 0 adds the N
+// contributions IN COPY ORDER (the summation order of the oracle, so results stay bit-identical) and
+// applies the priors and the Adam update.  4x the exposed parallelism of a one-thread-per-pixel loop for a
+// latency-bound gather, N * 256 bytes of LDS.
+constexpr int kBwdSplit = 4, kBwdPixX = 32, kBwdPixY = 2, kBwdPix = kBwdPixX * kBwdPixY;
+
 template <int LOG2F>
 __global__ __launch_bounds__(256) void sr_backward_adam_kernel(
     const float* __restrict__ x, float* __restrict__ x_new, const float* __restrict__ resid,
@@ -122,21 +135,26 @@ __global__ __launch_bounds__(256) void sr_backward_adam_kernel(
     float* __restrict__ m, float* __restrict__ v, float* __restrict__ vhat,
     const float* __restrict__ alphas /* [batch] for this iteration */, float* __restrict__ grad_out,
     SrDims d, float two_lambda_df, float lambda_tv, float two_lambda_l2, float lambda_l1, AdamArgs adam) {
-    const int X = blockIdx.x * kTileX + threadIdx.x;
-    const int Y = blockIdx.y * kTileY + threadIdx.y;
+    extern __shared__ float contrib[];                     // [n][kBwdPix]
+    const int X = blockIdx.x * kBwdPixX + threadIdx.x;
+    const int Y = blockIdx.y * kBwdPixY + threadIdx.y;
     const int b = blockIdx.z;
-    if (X >= d.W || Y >= d.H) return;
+    const int grp = threadIdx.z;                           // copy group == wave index
+    const int pix = threadIdx.y * kBwdPixX + threadIdx.x;
+    const bool in_image = (X < d.W) & (Y < d.H);
     const int H = d.H, W = d.W, f = d.f, lw = d.w, lh = d.h;
     const int ph0 = f / 2 - 1, ph1 = f / 2;
 
-    float g_df = 0.0f;
-    for (int n = 0; n < d.n; ++n) {
+    for (int n = grp; n < d.n; n += kBwdSplit) {
+        float g_df = 0.0f;
         const int bn = b * d.n + n;
         const float* r = resid + (int64_t)bn * lh * lw;
         const AsrTf8 ir = asr_load_tf(inv_rot_tf + (int64_t)bn * 8);
         const AsrTf8 it = asr_load_tf(inv_trans_tf + (int64_t)bn * 8);
-        auto gt_at = [&](int ly, int lx) -> float {
-            return (ly >= 0 && lx >= 0) ? (two_lambda_df * r[ly * lw + lx]) * 0.25f : 0.0f;
+        auto gt_at = [&](int ly, int lx) -> float {   // branch-free: clamped index, unconditional load, select
+            const bool ok = (ly >= 0) & (lx >= 0);
+            const float v = (two_lambda_df * r[ok ? ly * lw + lx : 0]) * 0.25f;
+            return ok ? v : 0.0f;
         };
         const bool pure_translation = (it.a0 == 1.0f && it.a1 == 0.0f && it.b0 == 0.0f && it.b1 == 1.0f &&
                                        it.c0 == 0.0f && it.c1 == 0.0f);
@@ -150,16 +168,48 @@ __global__ __launch_bounds__(256) void sr_backward_adam_kernel(
             const SrAxisTap ax1 = sr_axis_tap<LOG2F>(x0 + 1, it.a2, W, f, ph0, ph1);
             const SrAxisTap ay0 = sr_axis_tap<LOG2F>(y0, it.b2, H, f, ph0, ph1);
             const SrAxisTap ay1 = sr_axis_tap<LOG2F>(y0 + 1, it.b2, H, f, ph0, ph1);
-            auto gr = [&](const SrAxisTap& ay, const SrAxisTap& ax) -> float {   // G_R at one integer position
-                if (!(ay.inb && ax.inb)) return 0.0f;
-                const float vyf = ax.wl * gt_at(ay.l0, ax.l0) + ax.wh * gt_at(ay.l0, ax.l1);
-                const float vyc = ax.wl * gt_at(ay.l1, ax.l0) + ax.wh * gt_at(ay.l1, ax.l1);
-                return ay.wl * vyf + ay.wh * vyc;
+            // The 4 x 4 G_T taps under this pixel sit on 3 consecutive HR positions per axis, i.e. on at most
+            // 2 x 2 distinct LR residual cells: load those four values once and let every tap select its own
+            // (16 gathers -> 4; the texture-address path, not the VALU, bounded this kernel).
+            const int big = 0x3fffffff;
+            auto lo_of = [&](int a, int b2, int c, int e) {
+                return min(min(a >= 0 ? a : big, b2 >= 0 ? b2 : big), min(c >= 0 ? c : big, e >= 0 ? e : big));
             };
+            const int cxa = lo_of(ax0.l0, ax0.l1, ax1.l0, ax1.l1), cxb = max(max(ax0.l0, ax0.l1), max(ax1.l0, ax1.l1));
+            const int cya = lo_of(ay0.l0, ay0.l1, ay1.l0, ay1.l1), cyb = max(max(ay0.l0, ay0.l1), max(ay1.l0, ay1.l1));
+            auto in2 = [](int l, int a, int b2) { return (l < 0) | (l == a) | (l == b2); };
+            const bool two_cells = in2(ax0.l0, cxa, cxb) & in2(ax0.l1, cxa, cxb) & in2(ax1.l0, cxa, cxb) & in2(ax1.l1, cxa, cxb) &
+                                   in2(ay0.l0, cya, cyb) & in2(ay0.l1, cya, cyb) & in2(ay1.l0, cya, cyb) & in2(ay1.l1, cya, cyb);
             const float wxl = (xf + 1.0f) - ix, wxh = ix - xf;
-            const float vyf = wxl * gr(ay0, ax0) + wxh * gr(ay0, ax1);
-            const float vyc = wxl * gr(ay1, ax0) + wxh * gr(ay1, ax1);
-            g_df += ((yf + 1.0f) - iy) * vyf + (iy - yf) * vyc;
+            if (two_cells) {
+                const int xa = (cxa == big) ? 0 : cxa, xb = max(cxb, 0), ya = (cya == big) ? 0 : cya, yb = max(cyb, 0);
+                const float saa = (two_lambda_df * r[ya * lw + xa]) * 0.25f, sab = (two_lambda_df * r[ya * lw + xb]) * 0.25f;
+                const float sba = (two_lambda_df * r[yb * lw + xa]) * 0.25f, sbb = (two_lambda_df * r[yb * lw + xb]) * 0.25f;
+                auto gt_sel = [&](int ly, int lx) -> float {
+                    const float row_a = (lx == cxa) ? saa : sab, row_b = (lx == cxa) ? sba : sbb;
+                    const float v = (ly == cya) ? row_a : row_b;
+                    return ((ly >= 0) & (lx >= 0)) ? v : 0.0f;
+                };
+                auto gr = [&](const SrAxisTap& ay, const SrAxisTap& ax) -> float {   // G_R at one integer position
+                    const float vyf = ax.wl * gt_sel(ay.l0, ax.l0) + ax.wh * gt_sel(ay.l0, ax.l1);
+                    const float vyc = ax.wl * gt_sel(ay.l1, ax.l0) + ax.wh * gt_sel(ay.l1, ax.l1);
+                    const float v = ay.wl * vyf + ay.wh * vyc;
+                    return (ay.inb & ax.inb) ? v : 0.0f;
+                };
+                const float vyf = wxl * gr(ay0, ax0) + wxh * gr(ay0, ax1);
+                const float vyc = wxl * gr(ay1, ax0) + wxh * gr(ay1, ax1);
+                g_df += ((yf + 1.0f) - iy) * vyf + (iy - yf) * vyc;
+            } else {   // > 2 distinct cells on an axis: only through float rounding at a binade edge; 16 direct gathers
+                auto gr = [&](const SrAxisTap& ay, const SrAxisTap& ax) -> float {
+                    const float vyf = ax.wl * gt_at(ay.l0, ax.l0) + ax.wh * gt_at(ay.l0, ax.l1);
+                    const float vyc = ax.wl * gt_at(ay.l1, ax.l0) + ax.wh * gt_at(ay.l1, ax.l1);
+                    const float v = ay.wl * vyf + ay.wh * vyc;
+                    return (ay.inb & ax.inb) ? v : 0.0f;
+                };
+                const float vyf = wxl * gr(ay0, ax0) + wxh * gr(ay0, ax1);
+                const float vyc = wxl * gr(ay1, ax0) + wxh * gr(ay1, ax1);
+                g_df += ((yf + 1.0f) - iy) * vyf + (iy - yf) * vyc;
+            }
         } else {
             // generic projective inverse transforms (never produced by the reference's translate)
             auto rd_gt = [&](int yt, int xt) -> float {
@@ -171,7 +221,12 @@ __global__ __launch_bounds__(256) void sr_backward_adam_kernel(
             };
             g_df += asr_tf_sample(ir, rd_gr, X, Y);
         }
+        contrib[n * kBwdPix + pix] = g_df;
     }
+    __syncthreads();
+    if (grp != 0 || !in_image) return;
+    float g_df = 0.0f;
+    for (int n = 0; n < d.n; ++n) g_df += contrib[n * kBwdPix + pix];   // fixed order n = 0..N-1
 
     // priors (superresolution.py:81-98): TV (forward differences, last row/col 0), L2, L1
     const float* img = x + (int64_t)b * H * W;
@@ -308,6 +363,21 @@ int check_dims(const char* fn, int batch, int n, int H, int W, int h, int w, SrD
     return ASR_OK;
 }
 
+int prepare_backward(const SrDims& d) {
+    const size_t lds = sizeof(float) * (size_t)d.n * 64;
+    ASR_UNSUPPORTED(lds > 160 * 1024, "asr_sr: num_aug=%d needs %zu bytes of LDS in the backward kernel (max 640 copies)", d.n, lds);
+    static bool attr_set[4] = {false, false, false, false};
+    const int idx = d.f == 2 ? 1 : (d.f == 4 ? 2 : (d.f == 8 ? 3 : 0));
+    if (!attr_set[idx] && lds > 64 * 1024) {
+        ASR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(sr_backward_kernel_for(d.f)),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set[idx] = true;
+    }
+    return ASR_OK;
+}
+dim3 bwd_grid(const SrDims& d) { return dim3((unsigned)asr_cdiv(d.W, kBwdPixX), (unsigned)asr_cdiv(d.H, kBwdPixY), (unsigned)d.batch); }
+const dim3 kBwdBlock(kBwdPixX, kBwdPixY, kBwdSplit);
+size_t bwd_lds(const SrDims& d) { return sizeof(float) * (size_t)d.n * kBwdPix; }
 dim3 hr_grid(const SrDims& d) { return dim3((unsigned)asr_cdiv(d.W, kTileX), (unsigned)asr_cdiv(d.H, kTileY), (unsigned)d.batch); }
 dim3 lr_grid(const SrDims& d) { return dim3((unsigned)asr_cdiv(d.w, kTileX), (unsigned)asr_cdiv(d.h, kTileY), (unsigned)(d.batch * d.n)); }
 const dim3 kBlock(kTileX, kTileY);
@@ -354,7 +424,9 @@ extern "C" int asr_sr_backward_adam_f32(const float* x, float* x_new, const floa
     int rc = check_dims("asr_sr_backward_adam_f32", batch, n, H, W, h, w, &d);
     if (rc != ASR_OK) return rc;
     AdamArgs a{one_minus_beta1, one_minus_beta2, epsilon, amsgrad};
-    hipLaunchKernelGGL(sr_backward_kernel_for(d.f), hr_grid(d), kBlock, 0, asr_stream(stream), x, x_new, resid, inv_rot_tf,
+    rc = prepare_backward(d);
+    if (rc != ASR_OK) return rc;
+    hipLaunchKernelGGL(sr_backward_kernel_for(d.f), bwd_grid(d), kBwdBlock, bwd_lds(d), asr_stream(stream), x, x_new, resid, inv_rot_tf,
                        inv_trans_tf, m, v, vhat, alphas, grad_out, d, 2.0f * lambda_df, lambda_tv, 2.0f * lambda_l2,
                        lambda_l1, a);
     ASR_LAUNCH_CHECK();
@@ -409,6 +481,8 @@ extern "C" int asr_sr_solve_f32(float* x, const float* y, const float* rot_tf, c
     float* cur = x;
     float* nxt = x_alt;
     AdamArgs a{one_minus_beta1, one_minus_beta2, epsilon, amsgrad};
+    rc = prepare_backward(d);
+    if (rc != ASR_OK) return rc;
     const SrBwdKernel bwd_kernel = sr_backward_kernel_for(d.f);
     for (int it = 0; it < num_iter; ++it) {
         hipLaunchKernelGGL(sr_forward_residual_kernel, lr_grid(d), kBlock, 0, s, cur, y, rot_tf, trans_tf, resid, d);
@@ -417,7 +491,7 @@ extern "C" int asr_sr_solve_f32(float* x, const float* y, const float* rot_tf, c
             rc = asr_sr_loss_terms_f64(cur, resid, last_loss_terms, batch, n, H, W, h, w, stream);
             if (rc != ASR_OK) return rc;
         }
-        hipLaunchKernelGGL(bwd_kernel, hr_grid(d), kBlock, 0, s, cur, nxt, resid, inv_rot_tf, inv_trans_tf,
+        hipLaunchKernelGGL(bwd_kernel, bwd_grid(d), kBwdBlock, bwd_lds(d), s, cur, nxt, resid, inv_rot_tf, inv_trans_tf,
                            m, v, vhat, alphas + (size_t)it * batch, (float*)nullptr, d, 2.0f * lambda_df, lambda_tv,
                            2.0f * lambda_l2, lambda_l1, a);
         ASR_LAUNCH_CHECK();

@@ -25,6 +25,7 @@ class HotPath:
         self.mode = mode
         self.th_factor = th_factor
         self.batch_size = batch_size
+        self._side = None
 
     def _threshold(self, target, target_max):
         if target_max is not None:
@@ -42,12 +43,9 @@ class HotPath:
         am = ops.argmax(up)[0]
         return torch.where(am == self.class_id, am, torch.zeros_like(am))
 
-    def run_image(self, image_dev, angles, shifts, gt_dev=None, adam_start=None, profile=None,
-                  sr_types=("aug", "max", "mean"), want_standard=True):
-        """image_dev [H,W,3] float32 device; angles [N], shifts [N,2] float32 host arrays;
-        gt_dev [H,W] int32 device labels (optional).  Returns dict of device masks (+ 6 IoUs)."""
-        sr = self.sr
-        out_hw = sr.output_size
+    # ---- stage 1 (model stream): augment -> forward -> OPM (-> standard mask) --------------------------
+    def _stage_model(self, image_dev, angles, shifts, profile=None, want_standard=True):
+        out_hw = self.sr.output_size
         copies = au.augment_on_device(image_dev, angles, shifts)
         preds = self.model.predict_device(copies, batch_size=self.batch_size, profile=profile)
         del copies
@@ -58,11 +56,16 @@ class HotPath:
         del preds
         y = cls[None]
         ymax = mx[None] if mx is not None else None
-        a, s = angles[None], shifts[None]
         if self.mode != "slice":            # load_SR_data's global min-max normalisation (superres_utils.py:183-192)
             y = self._normalise(y)
             if ymax is not None:
                 ymax = self._normalise(ymax)
+        return res, y, ymax
+
+    # ---- stage 2 (any stream): ASR solve, max / mean realign, threshold, IoU counts --------------------
+    def _stage_sr(self, res, y, ymax, angles, shifts, gt_dev, adam_start, sr_types):
+        sr = self.sr
+        a, s = angles[None], shifts[None]
         for t in sr_types:
             if t == "aug":
                 if adam_start is not None:
@@ -74,7 +77,41 @@ class HotPath:
                 tmax = sr.realign_batch(ymax, a, s, t) if ymax is not None else None
             res[t] = self._threshold(tgt[0], tmax[0] if tmax is not None else None)
         if gt_dev is not None:
-            res["ious"] = self.iou_record(res, gt_dev)
+            res["_iou_keys"], res["_iou_counts"] = self._iou_counts(res, gt_dev)
+        return res
+
+    def run_image(self, image_dev, angles, shifts, gt_dev=None, adam_start=None, profile=None,
+                  sr_types=("aug", "max", "mean"), want_standard=True):
+        """image_dev [H,W,3] float32 device; angles [N], shifts [N,2] float32 host arrays;
+        gt_dev [H,W] int32 device labels (optional).  Returns dict of device masks (+ 6 IoUs)."""
+        res, y, ymax = self._stage_model(image_dev, angles, shifts, profile, want_standard)
+        res = self._stage_sr(res, y, ymax, angles, shifts, gt_dev, adam_start, sr_types)
+        return self._finish(res)
+
+    def submit_image(self, image_dev, angles, shifts, gt_dev=None, adam_start=None,
+                     sr_types=("aug", "max", "mean"), want_standard=True):
+        """Pipelined form: stage 1 on the current stream, stage 2 on a side HIP stream, so the latency-bound
+        SR solve of image i runs under the MFMA-bound forward pass of image i+1.  Returns a handle whose
+        .result() waits for the side stream and yields the same dict as run_image."""
+        main = torch.cuda.current_stream()
+        if self._side is None:
+            self._side = torch.cuda.Stream()
+        res, y, ymax = self._stage_model(image_dev, angles, shifts, None, want_standard)
+        ready = torch.cuda.Event()
+        ready.record(main)
+        with torch.cuda.stream(self._side):
+            self._side.wait_event(ready)
+            res = self._stage_sr(res, y, ymax, angles, shifts, gt_dev, adam_start, sr_types)
+            done = torch.cuda.Event()
+            done.record(self._side)
+        for t in [y, ymax] + [v for v in res.values() if isinstance(v, torch.Tensor)]:
+            if t is not None:
+                t.record_stream(self._side)          # allocated on the main stream, consumed on the side stream
+        return _Pending(self, res, done, keep=(y, ymax, gt_dev))
+
+    def _finish(self, res):
+        if "_iou_counts" in res:
+            res["ious"] = self._ious_from_counts(res.pop("_iou_keys"), res.pop("_iou_counts").cpu().numpy())
         return res
 
     @staticmethod
@@ -84,15 +121,17 @@ class HotPath:
         den = torch.where(den != 0, den, torch.ones_like(den))
         return ((stack - mm[0]) / den).contiguous()
 
-    def iou_record(self, res, gt_dev):
-        """[standard_single, standard_bg, aug_single, aug_bg, max, mean] (SR_single_class.py:109-120);
-        one small D2H copy of the integer counts."""
-        cid = self.class_id
+    def _iou_counts(self, res, gt_dev):
+        """Integer intersection / union counts of every produced mask against the ground truth (device)."""
         gt = gt_dev.reshape(-1).to(torch.int32)
         keys = [k for k in ("standard", "aug", "max", "mean") if k in res]
         preds = torch.stack([res[k].reshape(-1).to(torch.int32) for k in keys])
         truth = gt[None].expand(len(keys), -1).contiguous()
-        counts = ops.iou_counts(truth, preds, cid, include_bg=True, segments=len(keys)).cpu().numpy()
+        return keys, ops.iou_counts(truth, preds, self.class_id, include_bg=True, segments=len(keys))
+
+    @staticmethod
+    def _ious_from_counts(keys, counts):
+        """[standard_single, standard_bg, aug_single, aug_bg, max, mean] (SR_single_class.py:109-120)."""
         by = dict(zip(keys, counts))
         nan = float("nan")
 
@@ -101,3 +140,15 @@ class HotPath:
 
         return np.array([iou("standard", False), iou("standard", True), iou("aug", False), iou("aug", True),
                          iou("max", False), iou("mean", False)], dtype=np.float64)
+
+
+class _Pending:
+    """Handle of an image whose SR stage is still running on the side stream."""
+
+    def __init__(self, path, res, done, keep):
+        self._path, self._res, self._done, self._keep = path, res, done, keep
+
+    def result(self):
+        self._done.synchronize()
+        self._keep = None
+        return self._path._finish(self._res)

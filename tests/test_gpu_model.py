@@ -96,3 +96,39 @@ def test_hot_path_config1_test_cat(dev, synthetic, golden_dir, tmp_path):
         d = abs(np.nan_to_num(compute_IoU(gt, out[t], img_size=size, class_id=cls)) -
                 np.nan_to_num(o_aug.compute_IoU(o_gt, ref, img_size=size, class_id=cls)))
         assert d <= 1e-3, (t, d)
+
+
+def test_pipelined_submit_equals_sequential(dev, synthetic):
+    """The side-stream pipeline (SR of image i under the forward pass of image i+1) must give exactly the
+    masks and IoUs of the sequential path."""
+    from asr_amd import ops
+    from asr_amd.model import DeeplabModel
+    from asr_amd.pipeline import HotPath
+    from asr_amd.superresolution_scripts.optimizer import Optimizer
+    from asr_amd.superresolution_scripts.superresolution import Superresolution
+    from asr_amd.superresolution_scripts.augmentation_utils import draw_augmentation_parameters
+    size, feat, n_aug, iters = (128, 128), (32, 32), 6, 8
+    model = DeeplabModel(synthetic, size + (3,), 21, False, None)
+    rng = np.random.default_rng(5)
+    imgs = [ops.to_device(rng.random(size + (3,), dtype=np.float32)) for _ in range(3)]
+    gt = np.zeros(size, np.int32)
+    gt[30:90, 40:100] = 8
+    gtd = ops.to_device(gt, torch.int32)
+    np.random.seed(7)
+    params = [draw_augmentation_parameters(n_aug, 0.15, 20) for _ in imgs]
+
+    def make():
+        opt = Optimizer("adam", 1e-3, amsgrad=True, lr_scheduler=True, decay_steps=60, decay_rate=0.3)
+        sr = Superresolution(1.0, 0.3, 0.7, 0.0, num_iter=iters, num_aug=n_aug, optimizer=opt, feature_size=feat,
+                             output_size=size)
+        return HotPath(model, sr, class_id=8, mode="argmax", th_factor=0.2, batch_size=6)
+
+    seq = make()
+    ref = [seq.run_image(im, a, s, gt_dev=gtd, adam_start=i * iters) for i, (im, (a, s)) in enumerate(zip(imgs, params))]
+    pipe = make()
+    handles = [pipe.submit_image(im, a, s, gt_dev=gtd, adam_start=i * iters) for i, (im, (a, s)) in enumerate(zip(imgs, params))]
+    got = [h.result() for h in handles]
+    for r, g in zip(ref, got):
+        for k in ("standard", "aug", "max", "mean"):
+            assert torch.equal(r[k], g[k]), k
+        np.testing.assert_array_equal(r["ious"], g["ious"])
