@@ -118,7 +118,7 @@ def main():
     ap.add_argument("--precision", choices=["f16x3", "f32"], default=os.environ.get("ASR_PRECISION", "f16x3"),
                     help="pointwise GEMM arithmetic: f16x3 = split-f16 MFMA with f32 accumulation (f32-grade results), "
                          "f32 = v_mfma_f32_32x32x2_f32")
-    ap.add_argument("--no-overlap", action="store_true", help="run the SR stage on the main stream (no side-stream overlap)")
+    ap.add_argument("--overlap", action="store_true", help="run the SR stage of image i on a side HIP stream under the forward pass of image i+1 (measured: no gain, the GEMM waves already fill the register file)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -177,7 +177,7 @@ def main():
 
     def run_steps(first, count):
         recs = []
-        if args.no_overlap:
+        if not args.overlap:
             for i in range(first, first + count):
                 recs.append(step(i)["ious"])
             return recs
@@ -233,7 +233,7 @@ def main():
             "precision": args.precision,
             "images_per_gpu": K, "num_aug": NUM_AUG, "sr_iters": SR_ITERS, "forward_batch": args.batch_size,
             "parallelism": f"images sharded over {world} GPU(s), one all-gather of IoU records",
-            "overlap": "none" if args.no_overlap else "SR stage of image i on a side HIP stream under the forward pass of image i+1",
+            "overlap": "none" if not args.overlap else "SR stage of image i on a side HIP stream under the forward pass of image i+1",
         },
     }
     if rank == 0:

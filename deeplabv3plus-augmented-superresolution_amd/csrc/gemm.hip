@@ -288,10 +288,12 @@ __device__ __forceinline__ void split_f16x8(const f32x4& a, const f32x4& b, f16x
     }
 }
 
+template <bool DBUF>
 __global__ __launch_bounds__(256) void pw_gemm_f16x3_kernel(PwArgs p) {
     constexpr int WM = 2, WN = 2, TM = 2, TN = 2, BM = 128, BN = 128;
+    constexpr int STAGE = 2 * (BM * BK + BK * BN);   // halfs per LDS stage (A_hi, A_lo, B_hi, B_lo)
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    _Float16* const sAh = reinterpret_cast<_Float16*>(smem);   // 128 rows x 32 k
+    _Float16* const sAh = reinterpret_cast<_Float16*>(smem);   // 128 rows x 32 k      (+ stage offset)
     _Float16* const sAl = sAh + BM * BK;
     _Float16* const sBh = sAl + BM * BK;                         // 4 octets x 128 cols x 8
     _Float16* const sBl = sBh + BK * BN;
@@ -347,21 +349,22 @@ __global__ __launch_bounds__(256) void pw_gemm_f16x3_kernel(PwArgs p) {
             rbl[i] = *reinterpret_cast<const f16x8*>(wh + plane + off);
         }
     };
-    auto store_tile = [&]() {
+    auto store_tile = [&](int buf) {
+        const int so = buf * STAGE;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int row = (tid >> 2) + 64 * i;
             f16x8 hi, lo;
             split_f16x8(ra[i][0], ra[i][1], hi, lo);
-            const int off = (row * 4 + (a_oct ^ ((row >> 2) & 3))) * 8;
+            const int off = so + (row * 4 + (a_oct ^ ((row >> 2) & 3))) * 8;
             *reinterpret_cast<f16x8*>(sAh + off) = hi;
             *reinterpret_cast<f16x8*>(sAl + off) = lo;
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int slot = tid + 256 * i;
-            *reinterpret_cast<f16x8*>(sBh + slot * 8) = rbh[i];
-            *reinterpret_cast<f16x8*>(sBl + slot * 8) = rbl[i];
+            *reinterpret_cast<f16x8*>(sBh + so + slot * 8) = rbh[i];
+            *reinterpret_cast<f16x8*>(sBl + so + slot * 8) = rbl[i];
         }
     };
 
@@ -375,10 +378,11 @@ __global__ __launch_bounds__(256) void pw_gemm_f16x3_kernel(PwArgs p) {
 
     const int KT = (p.K + BK - 1) / BK;
     load_tile(0);
-    store_tile();
+    store_tile(0);
     __syncthreads();
     for (int kt = 0; kt < KT; ++kt) {
-        if (kt + 1 < KT) load_tile(kt + 1);
+        const int so = DBUF ? (kt & 1) * STAGE : 0;
+        if (kt + 1 < KT && !(p.debug & 2)) load_tile(kt + 1);
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             const int oct = 2 * s + hh;
@@ -386,15 +390,15 @@ __global__ __launch_bounds__(256) void pw_gemm_f16x3_kernel(PwArgs p) {
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 const int row = (wm * TM + i) * 32 + l32;
-                const int off = (row * 4 + (oct ^ ((row >> 2) & 3))) * 8;
+                const int off = so + (row * 4 + (oct ^ ((row >> 2) & 3))) * 8;
                 ah[i] = *reinterpret_cast<const f16x8*>(sAh + off);
                 al[i] = *reinterpret_cast<const f16x8*>(sAl + off);
             }
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int col = (wn * TN + j) * 32 + l32;
-                bh[j] = *reinterpret_cast<const f16x8*>(sBh + (oct * BN + col) * 8);
-                bl[j] = *reinterpret_cast<const f16x8*>(sBl + (oct * BN + col) * 8);
+                bh[j] = *reinterpret_cast<const f16x8*>(sBh + so + (oct * BN + col) * 8);
+                bl[j] = *reinterpret_cast<const f16x8*>(sBl + so + (oct * BN + col) * 8);
             }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
@@ -406,9 +410,14 @@ __global__ __launch_bounds__(256) void pw_gemm_f16x3_kernel(PwArgs p) {
                 }
         }
         if (kt + 1 < KT) {
-            __syncthreads();
-            store_tile();
-            __syncthreads();
+            if (DBUF) {
+                store_tile((kt + 1) & 1);
+                __syncthreads();
+            } else {
+                __syncthreads();
+                store_tile(0);
+                __syncthreads();
+            }
         }
     }
     __syncthreads();
@@ -598,7 +607,13 @@ extern "C" int asr_pwconv_mfma_f16x3(const float* x, const float* w_packed, cons
     const long long nwg = asr_cdiv(m, 128) * a.tiles_n;
     ASR_REQUIRE(nwg <= 0x7fffffffLL, "asr_pwconv_mfma_f16x3: grid too large");
     const size_t lds = sizeof(float) * (128 * BK + BK * 128);
-    hipLaunchKernelGGL(pw_gemm_f16x3_kernel, dim3((unsigned)nwg), dim3(256), lds, asr_stream(stream), a);
+    static const int dbg = getenv("ASR_GEMM_DEBUG") ? atoi(getenv("ASR_GEMM_DEBUG")) : 0;
+    static const int f16_variant = getenv("ASR_F16X3_VARIANT") ? atoi(getenv("ASR_F16X3_VARIANT")) : 0;
+    a.debug = dbg;
+    if (f16_variant == 1)
+        hipLaunchKernelGGL(pw_gemm_f16x3_kernel<true>, dim3((unsigned)nwg), dim3(256), 2 * lds, asr_stream(stream), a);
+    else
+        hipLaunchKernelGGL(pw_gemm_f16x3_kernel<false>, dim3((unsigned)nwg), dim3(256), lds, asr_stream(stream), a);
     ASR_LAUNCH_CHECK();
     return ASR_OK;
 }

@@ -73,8 +73,39 @@ __global__ __launch_bounds__(256) void sr_forward_residual_kernel(
 
     // D: half-pixel bilinear, even integer factor f -> taps (f*o + f/2 - 1, +1), lerp 0.5
     const int y0 = d.f * i + d.f / 2 - 1, x0 = d.f * j + d.f / 2 - 1;
-    const float tl = T(y0, x0), trv = T(y0, x0 + 1);
-    const float bl = T(y0 + 1, x0), br = T(y0 + 1, x0 + 1);
+    float tl, trv, bl, br;
+    // Pure translation (always, for tfa.image.translate): the four T pixels read a 3 x 3 block of R pixels
+    // (2 x 2 taps each, shifted by one); evaluate those 9 rotation samples once instead of 16 times.  Same
+    // per-tap arithmetic as the generic path, so the results are bit-identical; the generic path stays for
+    // other transforms and for the (float-rounding) case where the two tap columns / rows do not abut.
+    const bool pure_translation = (tt.a0 == 1.0f) & (tt.a1 == 0.0f) & (tt.b0 == 0.0f) & (tt.b1 == 1.0f) &
+                                  (tt.c0 == 0.0f) & (tt.c1 == 0.0f);
+    const float jx0 = (float)x0 + tt.a2, jx1 = (float)(x0 + 1) + tt.a2;
+    const float jy0 = (float)y0 + tt.b2, jy1 = (float)(y0 + 1) + tt.b2;
+    const float fx0 = floorf(jx0), fx1 = floorf(jx1), fy0 = floorf(jy0), fy1 = floorf(jy1);
+    const int cx0 = asr_coord_to_int(fx0), cx1 = asr_coord_to_int(fx1);
+    const int cy0 = asr_coord_to_int(fy0), cy1 = asr_coord_to_int(fy1);
+    if (pure_translation && cx1 == cx0 + 1 && cy1 == cy0 + 1) {
+        float rv[3][3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) rv[a][c] = rd_rot(cy0 + a, cx0 + c);
+        const float wxl0 = (fx0 + 1.0f) - jx0, wxh0 = jx0 - fx0, wxl1 = (fx1 + 1.0f) - jx1, wxh1 = jx1 - fx1;
+        const float wyl0 = (fy0 + 1.0f) - jy0, wyh0 = jy0 - fy0, wyl1 = (fy1 + 1.0f) - jy1, wyh1 = jy1 - fy1;
+        auto Tq = [&](int a, int c, float wxl, float wxh, float wyl, float wyh) -> float {
+            const float vyf = wxl * rv[a][c] + wxh * rv[a][c + 1];
+            const float vyc = wxl * rv[a + 1][c] + wxh * rv[a + 1][c + 1];
+            return wyl * vyf + wyh * vyc;
+        };
+        tl = Tq(0, 0, wxl0, wxh0, wyl0, wyh0);
+        trv = Tq(0, 1, wxl1, wxh1, wyl0, wyh0);
+        bl = Tq(1, 0, wxl0, wxh0, wyl1, wyh1);
+        br = Tq(1, 1, wxl1, wxh1, wyl1, wyh1);
+    } else {
+        tl = T(y0, x0); trv = T(y0, x0 + 1);
+        bl = T(y0 + 1, x0); br = T(y0 + 1, x0 + 1);
+    }
     const float top = tl + (trv - tl) * 0.5f;
     const float bot = bl + (br - bl) * 0.5f;
     const float dval = top + (bot - top) * 0.5f;
