@@ -1,0 +1,116 @@
+"""CPU tests of the host-side mirror: argument validation and error behaviour identical to the reference,
+float32 parameter math, plan bookkeeping -- nothing here touches a GPU."""
+import numpy as np
+import pytest
+
+
+def test_deeplab_constructor_validation_matches_reference():
+    """model.py:20-30, 66-68: same ValueErrors; out-of-scope options are refused loudly."""
+    from asr_amd.model import DeeplabV3Plus
+    with pytest.raises(ValueError, match="weights"):
+        DeeplabV3Plus(weights="imagenet")
+    with pytest.raises(ValueError, match="last_activation"):
+        DeeplabV3Plus(last_activation="relu")
+    with pytest.raises(ValueError, match="Backbone"):
+        DeeplabV3Plus(backbone="resnet")
+    with pytest.raises(NotImplementedError):
+        DeeplabV3Plus(backbone="mobilenet")
+    with pytest.raises(NotImplementedError):
+        DeeplabV3Plus(OS=8)
+    m = DeeplabV3Plus(input_shape=(512, 512, 3), classes=21, OS=16, last_activation=None, load_weights=True,
+                      backbone="xception")
+    with pytest.raises(ValueError, match="only_DCNN_output"):
+        m.build_model(only_DCNN_output=True, only_ASPP_output=True)
+    with pytest.raises(NotImplementedError):
+        m.build_model(only_ASPP_output=True)
+
+
+def test_optimizer_schedule_and_persistent_counter():
+    """optimizer.py:37-52 + SURVEY 3.3: lr_t = 1e-3 * 0.3^(i/60), alpha_t with the GLOBAL step that keeps
+    growing across solves."""
+    from asr_amd.superresolution_scripts.optimizer import Optimizer
+    from asr_amd import transforms as T
+    opt = Optimizer("adam", 1e-3, amsgrad=True, lr_scheduler=True, decay_steps=60, decay_rate=0.3)
+    a1 = opt.schedule_alphas(3)
+    assert opt.optimizer.iterations == 3 and a1.dtype == np.float32
+    for i in range(3):
+        lr = np.float32(1e-3) * np.float32(0.3) ** (np.float32(i) / np.float32(60))
+        exp = lr * np.sqrt(1 - np.float32(0.999) ** (i + 1)) / (1 - np.float32(0.9) ** (i + 1))
+        assert abs(a1[i] - exp) < 1e-9
+    a2 = opt.schedule_alphas(2)                      # second solve: schedule restarts, bias correction continues at t = 4
+    assert opt.optimizer.iterations == 5
+    assert abs(a2[0] - T.adam_alpha(1e-3, 0.9, 0.999, 4)) < 1e-12
+    assert float(T.exponential_decay_lr(1e-3, 60, 0.3, 60)) == pytest.approx(3e-4, rel=1e-6)
+    for name in ("adadelta", "adagrad", "adamax", "sgd"):
+        with pytest.raises(NotImplementedError):
+            Optimizer(name)
+    assert Optimizer("whatever").optimizer.amsgrad is False     # unknown names fall through to Adam, like the reference
+
+
+def test_transform_vectors_and_inverse():
+    from asr_amd import transforms as T
+    r = T.rotation_transforms(np.array([0.0, 0.3], np.float32), 512, 512)
+    assert r.shape == (2, 8) and r.dtype == np.float32
+    np.testing.assert_array_equal(r[0], [1, 0, 0, 0, 1, 0, 0, 0])
+    c, s = np.cos(np.float32(0.3)), np.sin(np.float32(0.3))
+    np.testing.assert_allclose(r[1, :6], [c, -s, (511 - (c * 511 - s * 511)) / 2, s, c, (511 - (s * 511 + c * 511)) / 2],
+                               rtol=1e-6)
+    t = T.translation_transforms(np.array([[3.5, -2.0]], np.float32))
+    np.testing.assert_array_equal(t[0], [1, 0, -3.5, 0, 1, 2.0, 0, 0])
+    np.testing.assert_array_equal(T.inverse_transforms(t)[0], [1, 0, 3.5, 0, 1, -2.0, 0, 0])
+    inv = T.inverse_transforms(r[1:2])
+    np.testing.assert_allclose(inv, T.rotation_transforms(np.array([-0.3], np.float32), 512, 512), atol=5e-5)
+
+
+def test_sr_object_surface_and_errors():
+    from asr_amd.superresolution_scripts.superresolution import Superresolution
+    from asr_amd.superresolution_scripts.augmentation_utils import create_augmented_copies_chunked
+    s = Superresolution(1, 0.3, 0.7, 0.0)
+    assert (s.num_iter, s.num_aug, s.feature_size, s.output_size, s.optimizer) == (200, 100, (64, 64), (512, 512), None)
+    with pytest.raises(NotImplementedError):
+        Superresolution(1, 0, 0, 0, use_BTV=True)
+    with pytest.raises(NotImplementedError):
+        Superresolution(1, 0, 0, 0, copy_dropout=0.1)
+    with pytest.raises(Exception, match="multiple"):          # augmentation_utils.py:31-32, raised before any GPU work
+        create_augmented_copies_chunked(np.zeros((8, 8, 3), np.float32), 150, 0.1, 3, chunk_size=100)
+
+
+def test_interchange_file_roundtrip_and_validity(tmp_path):
+    from asr_amd.superresolution_scripts import superres_utils as su
+    masks = np.zeros((6, 4, 4, 1), np.float32)
+    masks[:, 1:3, 1:3] = 8.0
+    mx = np.random.default_rng(0).random((6, 4, 4, 1)).astype(np.float32)
+    a, sh = np.arange(6, dtype=np.float32), np.ones((6, 2), np.float32)
+    p = su.save_SR_data(str(tmp_path / "x" / "17"), masks, mx, a, sh, "17", "slice_max", 0.15, 80)
+    assert su.list_precomputed_data_paths(str(tmp_path), sort=True) == [p]
+    cm, mm, a2, s2, name = su.load_SR_data(p, num_aug=5)
+    assert name == "17" and cm.shape == (5, 4, 4, 1) and mm.shape == (5, 4, 4, 1)
+    assert cm.max() == 1.0 and cm.min() == 0.0 and mm.max() <= 1.0          # min-max normalised (mode != slice)
+    np.testing.assert_array_equal(a2, a[:5])
+    with pytest.raises(Exception, match="invalid"):
+        su.load_SR_data(p, num_aug=7)
+    p2 = su.save_SR_data(str(tmp_path / "x" / "18"), masks, None, a, sh, "18", "slice", 0.15, 80)
+    cm2, mm2, *_ = su.load_SR_data(p2, num_aug=6)
+    assert mm2 is None and cm2.max() == 8.0                                  # slice mode is stored already normalised
+    np.testing.assert_allclose(su.min_max_normalization(np.array([2.0, 4.0, 6.0]), 0.0, 1.0), [0, 0.5, 1])
+
+
+def test_weight_inventory_and_folding():
+    from asr_amd import weights as W
+    inv = W.layer_inventory(21)
+    names = [n for _k, n, _d in inv]
+    assert len(names) == len(set(names))
+    assert "entry_flow_block2_separable_conv2_pointwise" in names and "logits_semantic" in names
+    assert [n for n in names if n.endswith("_shortcut")] == ["entry_flow_block1_shortcut", "entry_flow_block2_shortcut",
+                                                             "entry_flow_block3_shortcut", "exit_flow_block1_shortcut"]
+    assert W.layer_inventory(5)[-1][1] == "custom_logits_semantic"          # model.py:298-301
+    eps = {n: d["eps"] for k, n, d in inv if k == "bn"}
+    assert eps["aspp1_depthwise_BN"] == 1e-3 and eps["aspp0_BN"] == 1e-5 and eps["decoder_conv1_pointwise_BN"] == 1e-5
+    w = W.make_synthetic_weights(7, 21)
+    assert w["entry_flow_conv1_1/kernel"].shape == (3, 3, 3, 32) and w["logits_semantic/bias"].shape == (21,)
+    k, b = W.fold_conv_bn(w, "aspp0", "aspp0_BN", 1e-5)
+    assert k.shape == (2048, 256) and b.shape == (256,)
+    with pytest.raises(ValueError):
+        W.load_weights("https://example.com/w.h5")
+    with pytest.raises(ValueError):
+        W.load_weights("/tmp/w.h5")
