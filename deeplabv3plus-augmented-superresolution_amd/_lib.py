@@ -48,6 +48,7 @@ SIGNATURES = {
     "asr_realign_max_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "asr_realign_mean_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "asr_minmax_f32": (_i, [_vp, _vp, _i64, _i, _vp]),
+    "asr_class_activation_f32": (_i, [_vp, _vp, _i64, _i, _i, _vp]),
     "asr_argmax_i32": (_i, [_vp, _vp, _i64, _i, _vp]),
     "asr_opm_argmax_f32": (_i, [_vp, _vp, _i64, _i, _i, _vp]),
     "asr_opm_slice_max_f32": (_i, [_vp, _vp, _vp, _i64, _i, _i, _vp]),

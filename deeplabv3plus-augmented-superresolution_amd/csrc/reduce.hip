@@ -135,6 +135,24 @@ __global__ __launch_bounds__(256) void iou_counts_kernel(const int32_t* __restri
     }
 }
 
+// ---- last_activation: softmax / sigmoid over the class axis (model.py:124-125) ----------------------
+__global__ __launch_bounds__(256) void class_activation_kernel(const float* __restrict__ logits, float* __restrict__ out,
+                                                              int64_t pixels, int classes, int kind) {
+    for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < pixels; p += (int64_t)gridDim.x * 256) {
+        const float* row = logits + p * classes;
+        float* o = out + p * classes;
+        if (kind == 1) {                       // softmax: exp(x - max) / sum
+            float mx = row[0];
+            for (int c = 1; c < classes; ++c) mx = fmaxf(mx, row[c]);
+            float sum = 0.f;
+            for (int c = 0; c < classes; ++c) sum += expf(row[c] - mx);
+            for (int c = 0; c < classes; ++c) o[c] = expf(row[c] - mx) / sum;
+        } else {                               // sigmoid
+            for (int c = 0; c < classes; ++c) o[c] = 1.0f / (1.0f + expf(-row[c]));
+        }
+    }
+}
+
 int stream_grid(int64_t n) {
     int64_t g = asr_cdiv(n, 256);
     return (int)(g < 2048 ? (g > 0 ? g : 1) : 2048);
@@ -218,6 +236,16 @@ extern "C" int asr_iou_counts_i32(const int32_t* truth, const int32_t* pred, int
     hipLaunchKernelGGL(iou_counts_kernel, dim3(stream_grid(per_segment) > 256 ? 256 : stream_grid(per_segment), segments),
                        dim3(256), 0, s, truth, pred, reinterpret_cast<unsigned long long*>(counts), per_segment, class_id,
                        include_bg);
+    ASR_LAUNCH_CHECK();
+    return ASR_OK;
+}
+
+extern "C" int asr_class_activation_f32(const float* logits, float* out, int64_t pixels, int classes, int kind,
+                                        asr_stream_t stream) {
+    ASR_REQUIRE(logits && out, "asr_class_activation_f32: null pointer");
+    ASR_REQUIRE(pixels > 0 && classes > 0 && (kind == 1 || kind == 2), "asr_class_activation_f32: bad arguments (kind 1 = softmax, 2 = sigmoid)");
+    hipLaunchKernelGGL(class_activation_kernel, dim3(stream_grid(pixels)), dim3(256), 0, asr_stream(stream), logits, out, pixels,
+                       classes, kind);
     ASR_LAUNCH_CHECK();
     return ASR_OK;
 }

@@ -94,10 +94,8 @@ class DeeplabModel:
                 logits = logits.clone()
             outs.append(logits)
         out = outs[0] if len(outs) == 1 else torch.cat(outs, dim=0)
-        if self.last_activation == "softmax":
-            out = torch.softmax(out, dim=-1)     # device-side torch op (not on the measured path)
-        elif self.last_activation == "sigmoid":
-            out = torch.sigmoid(out)
+        if self.last_activation in ("softmax", "sigmoid"):
+            out = ops.class_activation(out.contiguous(), self.last_activation)
         return out
 
     def _upsample(self, logits, hw):

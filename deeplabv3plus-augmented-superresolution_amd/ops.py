@@ -176,6 +176,15 @@ def minmax(x, segments=1):
     return out
 
 
+def class_activation(logits, kind):
+    """softmax / sigmoid over the last (class) axis, in a new tensor."""
+    classes = logits.shape[-1]
+    out = torch.empty_like(logits)
+    call("asr_class_activation_f32", ptr(logits), ptr(out), logits.numel() // classes, classes,
+         {"softmax": 1, "sigmoid": 2}[kind], stream_ptr())
+    return out
+
+
 def argmax(logits):
     classes = logits.shape[-1]
     pixels = logits.numel() // classes

@@ -123,6 +123,11 @@ int asr_realign_mean_f32(const float* y, float* out, const float* trans_tf, cons
  * augmentation_utils.py:100-101, superres_utils.py:134). */
 int asr_minmax_f32(const float* x, float* out_minmax, int64_t per_segment, int segments, asr_stream_t stream);
 
+/* Activation(last_activation) over the class axis (model.py:124-125): kind 1 = softmax, 2 = sigmoid.
+ * out may alias logits. */
+int asr_class_activation_f32(const float* logits, float* out, int64_t pixels, int classes, int kind,
+                             asr_stream_t stream);
+
 /* create_mask: argmax over the class axis, first maximum wins (utils.py:115-119). */
 int asr_argmax_i32(const float* logits, int32_t* out, int64_t pixels, int classes, asr_stream_t stream);
 

@@ -31,9 +31,15 @@ def test_two_stage_scripts(dev, golden_dir, tmp_path):
          str(tmp_path))
     data_dir = out_root / "xception_argmax_8_4"
     assert (data_dir / "7.npz").exists()
+    std_root = tmp_path / "standard"
+    _run([os.path.join(ROOT, "scripts", "generate_standard_output.py"), "--images", str(imgs), "--class_id", "8",
+          "--out_root", str(std_root)], str(tmp_path))
+    std_dir = std_root / "xception_8"
+    assert (std_dir / "7.png").exists()
     out = _run([os.path.join(ROOT, "scripts", "SR_single_class.py"), "--data", str(data_dir), "--gt", str(gts),
-                "--num_aug", "4", "--class_id", "8", "--out", str(tmp_path / "sr_out")], str(tmp_path))
-    assert "Avg. Max SR IoUs" in out and "Avg. Augmented SR IoUs" in out
+                "--standard", str(std_dir), "--num_aug", "4", "--class_id", "8", "--out", str(tmp_path / "sr_out")],
+               str(tmp_path))
+    assert "Avg. Max SR IoUs" in out and "Avg. Augmented SR IoUs" in out and "Avg. Standard IoUs (No bg): nan" not in out
 
 
 def test_single_image_demo(dev, tmp_path):
