@@ -136,8 +136,8 @@ def main():
 
     rank, world, local_rank = D.init_from_env()
     assert world == args.gpus or world == 1, f"WORLD_SIZE={world} but --gpus {args.gpus}"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev = D.local_device(local_rank)
+    torch.cuda.set_device(dev)
 
     K, Wm = args.steps, args.warmup
     per_rank = K + Wm
@@ -206,10 +206,7 @@ def main():
     barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = D.all_reduce_max(elapsed, dev)           # MAX over ranks
 
     copies_total = K * NUM_AUG * world
     out = {

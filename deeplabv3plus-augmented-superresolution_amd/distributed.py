@@ -34,11 +34,33 @@ def init_from_env(backend=None):
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # ASR_DIST_BACKEND=gloo rehearses the multi-rank path on a single-GPU box (RCCL refuses two ranks on one
+            # device); on a real node the default is nccl (= RCCL over xGMI).
+            backend = os.environ.get("ASR_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local_rank
+
+
+def local_device(local_rank):
+    """cuda:<local_rank>, wrapped onto the visible devices (a rehearsal with more ranks than GPUs shares devices)."""
+    n = torch.cuda.device_count()
+    return torch.device("cuda", local_rank % max(n, 1))
+
+
+def collective_device(device):
+    """Where collective payloads must live: the GPU for RCCL, host memory for gloo."""
+    return device if (dist.is_initialized() and dist.get_backend() == "nccl") else torch.device("cpu")
+
+
+def all_reduce_max(value, device):
+    """MAX over ranks of a host float (the bench's elapsed time)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=collective_device(device))
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
 
 
 def shard_indices(num_images, rank, world):
@@ -77,6 +99,7 @@ def all_gather_iou(local_indices, local_records, num_images, device=None):
     cap = -(-num_images // world)                       # equal-sized slots: ceil(images / world)
     if device is None:
         device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    device = collective_device(device)
     slot = torch.full((cap, 1 + len(IOU_FIELDS)), -1.0, dtype=torch.float64)
     slot[:len(idx), 0] = torch.from_numpy(idx.astype(np.float64))
     slot[:len(idx), 1:] = torch.from_numpy(rec)
