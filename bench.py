@@ -249,13 +249,20 @@ def main():
             with open(pmc_path) as fh:
                 pmc = json.load(fh)
 
+        def pmc_lookup(prefix):
+            """Launch-weighted mean HBM bytes of the entries whose kernel name starts with ``prefix`` (template
+            arguments in the name vary by build)."""
+            hits = [(v["hbm_bytes_per_launch"], v.get("launches_sampled", 1)) for k, v in pmc.items()
+                    if k.startswith(prefix) and v.get("hbm_bytes_per_launch") is not None]
+            return round(sum(b * n for b, n in hits) / sum(n for _, n in hits)) if hits else None
+
         def gemm_roofline(kind, kernel, pmc_key, peak, peak_note):
             ms, flops, nbytes, launches = prof[kind]
             achieved = flops / (ms * 1e-3) / 1e12
             return {
                 "kernel": kernel, "bound": "mfma", "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(achieved / peak, 4), "peak_note": peak_note,
-                "traffic": pmc.get(pmc_key, {}).get("hbm_bytes_per_launch"),
+                "traffic": pmc_lookup(pmc_key),
                 "traffic_note": "HBM bytes per launch from profiles/r01_pmc_traffic.json (separate FETCH_SIZE / WRITE_SIZE "
                                 "passes, FETCH doubled per the gfx950 rule)",
                 "algorithmic_bytes_per_launch": round(nbytes / launches),
@@ -267,16 +274,16 @@ def main():
 
         if "pw16" in prof:
             out["roofline"] = gemm_roofline(
-                "pw16", "pw_gemm_f16x3_kernel (asr_pwconv_mfma_f16x3, v_mfma_f32_32x32x16_f16 x3)", "pw_gemm_f16x3_kernel",
+                "pw16", "pw_gemm_f16x3_kernel (asr_pwconv_mfma_f16x3, v_mfma_f32_32x32x16_f16 x3)", "pw_gemm_f16x3_kernel<",
                 round(F16_MFMA_PEAK_TFLOPS / 3.0, 1),
                 "dense f16 MFMA peak 2500 TFLOP/s / 3 MFMA products per f32-grade product")
             if "pw" in prof:
                 out["roofline_f32_mfma_layers"] = gemm_roofline(
-                    "pw", "pw_gemm_kernel (layers with <= 64 output channels)", "pw_gemm_kernel<2, 2, 2, 1, false, false>",
+                    "pw", "pw_gemm_kernel (layers with <= 64 output channels)", "pw_gemm_kernel<2, 2, 2, 1,",
                     F32_MFMA_PEAK_TFLOPS, "FP32 MFMA peak (spec)")
         else:
             out["roofline"] = gemm_roofline("pw", "pw_gemm_kernel (asr_pwconv_mfma_f32, v_mfma_f32_32x32x2_f32)",
-                                            "pw_gemm_kernel<2, 2, 2, 2, false, false>", F32_MFMA_PEAK_TFLOPS,
+                                            "pw_gemm_kernel<2, 2, 2, 2,", F32_MFMA_PEAK_TFLOPS,
                                             "FP32 MFMA peak 157.3 TFLOP/s (spec)")
         if "dw" in prof:
             dms, _dfl, dby, dl = prof["dw"]

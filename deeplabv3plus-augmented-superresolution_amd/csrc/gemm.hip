@@ -288,15 +288,19 @@ __device__ __forceinline__ void split_f16x8(const f32x4& a, const f32x4& b, f16x
     }
 }
 
-template <bool DBUF>
-__global__ __launch_bounds__(256) void pw_gemm_f16x3_kernel(PwArgs p) {
+template <int BKT, bool DBUF, int MINW>
+__global__ __launch_bounds__(256, MINW) void pw_gemm_f16x3_kernel(PwArgs p) {
     constexpr int WM = 2, WN = 2, TM = 2, TN = 2, BM = 128, BN = 128;
-    constexpr int STAGE = 2 * (BM * BK + BK * BN);   // halfs per LDS stage (A_hi, A_lo, B_hi, B_lo)
+    constexpr int OCT = BKT / 8;                       // 16-byte slots (8 halfs) per tile row
+    constexpr int SWZ = OCT - 1;                       // XOR mask over the slots of a row
+    constexpr int SWZ_SHIFT = (OCT == 4) ? 2 : 1;      // rows per 256-byte bank row: 4 x 64 B or 2 x 128 B
+    constexpr int PER_THREAD = OCT / 2;                // (128 rows * OCT slots) / 256 threads
+    constexpr int STAGE = 2 * (BM * BKT + BKT * BN);   // halfs per LDS stage (A_hi, A_lo, B_hi, B_lo)
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    _Float16* const sAh = reinterpret_cast<_Float16*>(smem);   // 128 rows x 32 k      (+ stage offset)
-    _Float16* const sAl = sAh + BM * BK;
-    _Float16* const sBh = sAl + BM * BK;                         // 4 octets x 128 cols x 8
-    _Float16* const sBl = sBh + BK * BN;
+    _Float16* const sAh = reinterpret_cast<_Float16*>(smem);   // [128 rows][BKT]      (+ stage offset)
+    _Float16* const sAl = sAh + BM * BKT;
+    _Float16* const sBh = sAl + BM * BKT;                        // [OCT][128 cols][8]
+    _Float16* const sBl = sBh + BKT * BN;
 
     const int nwg = gridDim.x, orig = blockIdx.x;
     const int q8 = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
@@ -306,12 +310,13 @@ __global__ __launch_bounds__(256) void pw_gemm_f16x3_kernel(PwArgs p) {
     const int wm = wave / WN, wn = wave % WN;
     const int l32 = lane & 31, hh = lane >> 5;
 
-    // A staging: thread owns octet (tid & 3) of rows (tid >> 2) and 64 + (tid >> 2)
-    const int a_oct = tid & 3;
-    const float* a_base[2];
+    // A staging: thread owns slot (tid % OCT) of rows (tid / OCT) + i * (256 / OCT)
+    const int a_oct = tid % OCT;
+    constexpr int ROWS_PER_PASS = 256 / OCT;
+    const float* a_base[PER_THREAD];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int row = (tid >> 2) + 64 * i;
+    for (int i = 0; i < PER_THREAD; ++i) {
+        const int row = tid / OCT + ROWS_PER_PASS * i;
         const long long m = (long long)tile_m * BM + row;
         a_base[i] = nullptr;
         if (m < p.M) {
@@ -328,40 +333,46 @@ __global__ __launch_bounds__(256) void pw_gemm_f16x3_kernel(PwArgs p) {
     }
     const long long plane = (long long)p.Kpad * p.Npad;          // halfs per weight plane
     const _Float16* const wh = reinterpret_cast<const _Float16*>(p.wp) + (long long)tile_n * BN * 8;
-    f32x4 ra[2][2];
-    f16x8 rbh[2], rbl[2];
+    f32x4 ra[PER_THREAD][2];
+    f16x8 rbh[PER_THREAD], rbl[PER_THREAD];
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
     auto load_tile = [&](int kt) {
-        const int k0 = kt * BK;
+        const int k0 = kt * BKT;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < PER_THREAD; ++i) {
             const int k = k0 + a_oct * 8;
             ra[i][0] = (a_base[i] && k < p.K) ? *reinterpret_cast<const f32x4*>(a_base[i] + k) : zero4;
             ra[i][1] = (a_base[i] && k + 4 < p.K) ? *reinterpret_cast<const f32x4*>(a_base[i] + k + 4) : zero4;
         }
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < PER_THREAD; ++i) {
             const int slot = tid + 256 * i;
             const int oct = slot >> 7, n = slot & 127;
-            const long long off = ((long long)(k0 / 8 + oct) * p.Npad + n) * 8;
-            rbh[i] = *reinterpret_cast<const f16x8*>(wh + off);
-            rbl[i] = *reinterpret_cast<const f16x8*>(wh + plane + off);
+            const int ko = k0 / 8 + oct;
+            if (BKT == 32 || ko * 8 < p.Kpad) {
+                const long long off = ((long long)ko * p.Npad + n) * 8;
+                rbh[i] = *reinterpret_cast<const f16x8*>(wh + off);
+                rbl[i] = *reinterpret_cast<const f16x8*>(wh + plane + off);
+            } else {                                   // BKT = 64 over a K padded to 32: last half-tile is empty
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { rbh[i][j] = (_Float16)0.f; rbl[i][j] = (_Float16)0.f; }
+            }
         }
     };
     auto store_tile = [&](int buf) {
         const int so = buf * STAGE;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int row = (tid >> 2) + 64 * i;
+        for (int i = 0; i < PER_THREAD; ++i) {
+            const int row = tid / OCT + ROWS_PER_PASS * i;
             f16x8 hi, lo;
             split_f16x8(ra[i][0], ra[i][1], hi, lo);
-            const int off = so + (row * 4 + (a_oct ^ ((row >> 2) & 3))) * 8;
+            const int off = so + (row * OCT + (a_oct ^ ((row >> SWZ_SHIFT) & SWZ))) * 8;
             *reinterpret_cast<f16x8*>(sAh + off) = hi;
             *reinterpret_cast<f16x8*>(sAl + off) = lo;
         }
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < PER_THREAD; ++i) {
             const int slot = tid + 256 * i;
             *reinterpret_cast<f16x8*>(sBh + so + slot * 8) = rbh[i];
             *reinterpret_cast<f16x8*>(sBl + so + slot * 8) = rbl[i];
@@ -376,7 +387,7 @@ __global__ __launch_bounds__(256) void pw_gemm_f16x3_kernel(PwArgs p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    const int KT = (p.K + BK - 1) / BK;
+    const int KT = (p.K + BKT - 1) / BKT;
     load_tile(0);
     store_tile(0);
     __syncthreads();
@@ -384,13 +395,13 @@ __global__ __launch_bounds__(256) void pw_gemm_f16x3_kernel(PwArgs p) {
         const int so = DBUF ? (kt & 1) * STAGE : 0;
         if (kt + 1 < KT && !(p.debug & 2)) load_tile(kt + 1);
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
+        for (int s = 0; s < BKT / 16; ++s) {
             const int oct = 2 * s + hh;
             f16x8 ah[TM], al[TM], bh[TN], bl[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 const int row = (wm * TM + i) * 32 + l32;
-                const int off = so + (row * 4 + (oct ^ ((row >> 2) & 3))) * 8;
+                const int off = so + (row * OCT + (oct ^ ((row >> SWZ_SHIFT) & SWZ))) * 8;
                 ah[i] = *reinterpret_cast<const f16x8*>(sAh + off);
                 al[i] = *reinterpret_cast<const f16x8*>(sAl + off);
             }
@@ -610,10 +621,21 @@ extern "C" int asr_pwconv_mfma_f16x3(const float* x, const float* w_packed, cons
     static const int dbg = getenv("ASR_GEMM_DEBUG") ? atoi(getenv("ASR_GEMM_DEBUG")) : 0;
     static const int f16_variant = getenv("ASR_F16X3_VARIANT") ? atoi(getenv("ASR_F16X3_VARIANT")) : 0;
     a.debug = dbg;
-    if (f16_variant == 1)
-        hipLaunchKernelGGL(pw_gemm_f16x3_kernel<true>, dim3((unsigned)nwg), dim3(256), 2 * lds, asr_stream(stream), a);
-    else
-        hipLaunchKernelGGL(pw_gemm_f16x3_kernel<false>, dim3((unsigned)nwg), dim3(256), lds, asr_stream(stream), a);
+    if (f16_variant == 1) {
+        hipLaunchKernelGGL((pw_gemm_f16x3_kernel<32, true, 1>), dim3((unsigned)nwg), dim3(256), 2 * lds, asr_stream(stream), a);
+    } else if (f16_variant == 2) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            ASR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pw_gemm_f16x3_kernel<64, false, 1>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * lds)));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL((pw_gemm_f16x3_kernel<64, false, 1>), dim3((unsigned)nwg), dim3(256), 2 * lds, asr_stream(stream), a);
+    } else if (f16_variant == 3) {
+        hipLaunchKernelGGL((pw_gemm_f16x3_kernel<32, false, 4>), dim3((unsigned)nwg), dim3(256), lds, asr_stream(stream), a);
+    } else {
+        hipLaunchKernelGGL((pw_gemm_f16x3_kernel<32, false, 1>), dim3((unsigned)nwg), dim3(256), lds, asr_stream(stream), a);
+    }
     ASR_LAUNCH_CHECK();
     return ASR_OK;
 }
