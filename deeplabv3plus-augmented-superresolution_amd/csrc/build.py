@@ -55,7 +55,7 @@ def build(force=False, verbose=True):
         o = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
         objs.append(o)
         if force or _stale(o, [s] + hdrs):
-            cmd = [hipcc] + COMMON + extra + ["-c", s, "-o", o]
+            cmd = [hipcc] + COMMON + extra + os.environ.get("ASR_EXTRA_HIPFLAGS", "").split() + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)

@@ -288,19 +288,38 @@ __device__ __forceinline__ void split_f16x8(const f32x4& a, const f32x4& b, f16x
     }
 }
 
-template <int BKT, bool DBUF, int MINW>
-__global__ __launch_bounds__(256, MINW) void pw_gemm_f16x3_kernel(PwArgs p) {
-    constexpr int WM = 2, WN = 2, TM = 2, TN = 2, BM = 128, BN = 128;
-    constexpr int OCT = BKT / 8;                       // 16-byte slots (8 halfs) per tile row
-    constexpr int SWZ = OCT - 1;                       // XOR mask over the slots of a row
-    constexpr int SWZ_SHIFT = (OCT == 4) ? 2 : 1;      // rows per 256-byte bank row: 4 x 64 B or 2 x 128 B
-    constexpr int PER_THREAD = OCT / 2;                // (128 rows * OCT slots) / 256 threads
-    constexpr int STAGE = 2 * (BM * BKT + BKT * BN);   // halfs per LDS stage (A_hi, A_lo, B_hi, B_lo)
+// Phase timing of the K loop (tools/gemm_phase_profile.sh builds with -DASR_GEMM_PHASE_PROFILE; never in the product build):
+// wave 0 of every block accumulates shader-clock deltas per phase and the launcher prints their means.
+#ifdef ASR_GEMM_PHASE_PROFILE
+#define ASR_PHASE_BLOCKS 8192
+__device__ long long g_phase_cycles[ASR_PHASE_BLOCKS * 8];
+#define PHASE_MARK(i)                                              \
+    do {                                                           \
+        const long long now_ = (long long)__builtin_readcyclecounter(); \
+        ph[i] += now_ - tprev;                                     \
+        tprev = now_;                                              \
+    } while (0)
+#define PHASE_WAIT_VM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#define PHASE_WAIT_LGKM() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#else
+#define PHASE_MARK(i)
+#define PHASE_WAIT_VM()
+#define PHASE_WAIT_LGKM()
+#endif
+
+template <int WM, int WN, int TM, int TN, bool DBUF, int MINW>
+__global__ __launch_bounds__(WM * WN * 64, MINW) void pw_gemm_f16x3_kernel(PwArgs p) {
+    constexpr int NT = WM * WN * 64, BM = WM * TM * 32, BN = WN * TN * 32;
+    constexpr int PA = BM * 4 / NT;                    // (row, 32-byte k-slot) items of the A tile per thread
+    constexpr int PB = BN * 4 / NT;                    // (k-octet, column) items of the B tile per thread and plane
+    static_assert((BM * 4) % NT == 0 && (BN * 4) % NT == 0 && (BN & (BN - 1)) == 0, "tile / thread-count mismatch");
+    constexpr int STAGE = 2 * BK * (BM + BN);          // halfs per LDS stage (A_hi, A_lo, B_hi, B_lo)
+    // dynamic LDS = max(stages, epilogue staging of WM*WN waves x 32 x TN*32 floats), sized by the launcher
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    _Float16* const sAh = reinterpret_cast<_Float16*>(smem);   // [128 rows][BKT]      (+ stage offset)
-    _Float16* const sAl = sAh + BM * BKT;
-    _Float16* const sBh = sAl + BM * BKT;                        // [OCT][128 cols][8]
-    _Float16* const sBl = sBh + BKT * BN;
+    _Float16* const sAh = reinterpret_cast<_Float16*>(smem);   // [BM rows][32]          (+ stage offset)
+    _Float16* const sAl = sAh + BM * BK;
+    _Float16* const sBh = sAl + BM * BK;                        // [4 octets][BN cols][8]
+    _Float16* const sBl = sBh + BK * BN;
 
     const int nwg = gridDim.x, orig = blockIdx.x;
     const int q8 = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
@@ -310,13 +329,12 @@ __global__ __launch_bounds__(256, MINW) void pw_gemm_f16x3_kernel(PwArgs p) {
     const int wm = wave / WN, wn = wave % WN;
     const int l32 = lane & 31, hh = lane >> 5;
 
-    // A staging: thread owns slot (tid % OCT) of rows (tid / OCT) + i * (256 / OCT)
-    const int a_oct = tid % OCT;
-    constexpr int ROWS_PER_PASS = 256 / OCT;
-    const float* a_base[PER_THREAD];
+    // A staging: thread owns k-slot (tid % 4) of rows (tid / 4) + i * (NT / 4)
+    const int a_oct = tid & 3;
+    const float* a_base[PA];
 #pragma unroll
-    for (int i = 0; i < PER_THREAD; ++i) {
-        const int row = tid / OCT + ROWS_PER_PASS * i;
+    for (int i = 0; i < PA; ++i) {
+        const int row = (tid >> 2) + (NT / 4) * i;
         const long long m = (long long)tile_m * BM + row;
         a_base[i] = nullptr;
         if (m < p.M) {
@@ -333,47 +351,40 @@ __global__ __launch_bounds__(256, MINW) void pw_gemm_f16x3_kernel(PwArgs p) {
     }
     const long long plane = (long long)p.Kpad * p.Npad;          // halfs per weight plane
     const _Float16* const wh = reinterpret_cast<const _Float16*>(p.wp) + (long long)tile_n * BN * 8;
-    f32x4 ra[PER_THREAD][2];
-    f16x8 rbh[PER_THREAD], rbl[PER_THREAD];
+    f32x4 ra[PA][2];
+    f16x8 rbh[PB], rbl[PB];
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
     auto load_tile = [&](int kt) {
-        const int k0 = kt * BKT;
+        const int k = kt * BK + a_oct * 8;
 #pragma unroll
-        for (int i = 0; i < PER_THREAD; ++i) {
-            const int k = k0 + a_oct * 8;
+        for (int i = 0; i < PA; ++i) {
             ra[i][0] = (a_base[i] && k < p.K) ? *reinterpret_cast<const f32x4*>(a_base[i] + k) : zero4;
             ra[i][1] = (a_base[i] && k + 4 < p.K) ? *reinterpret_cast<const f32x4*>(a_base[i] + k + 4) : zero4;
         }
 #pragma unroll
-        for (int i = 0; i < PER_THREAD; ++i) {
-            const int slot = tid + 256 * i;
-            const int oct = slot >> 7, n = slot & 127;
-            const int ko = k0 / 8 + oct;
-            if (BKT == 32 || ko * 8 < p.Kpad) {
-                const long long off = ((long long)ko * p.Npad + n) * 8;
-                rbh[i] = *reinterpret_cast<const f16x8*>(wh + off);
-                rbl[i] = *reinterpret_cast<const f16x8*>(wh + plane + off);
-            } else {                                   // BKT = 64 over a K padded to 32: last half-tile is empty
-#pragma unroll
-                for (int j = 0; j < 8; ++j) { rbh[i][j] = (_Float16)0.f; rbl[i][j] = (_Float16)0.f; }
-            }
+        for (int i = 0; i < PB; ++i) {
+            const int slot = tid + NT * i;
+            const int oct = slot / BN, n = slot & (BN - 1);
+            const long long off = ((long long)(kt * 4 + oct) * p.Npad + n) * 8;
+            rbh[i] = *reinterpret_cast<const f16x8*>(wh + off);
+            rbl[i] = *reinterpret_cast<const f16x8*>(wh + plane + off);
         }
     };
     auto store_tile = [&](int buf) {
         const int so = buf * STAGE;
 #pragma unroll
-        for (int i = 0; i < PER_THREAD; ++i) {
-            const int row = tid / OCT + ROWS_PER_PASS * i;
+        for (int i = 0; i < PA; ++i) {
+            const int row = (tid >> 2) + (NT / 4) * i;
             f16x8 hi, lo;
             split_f16x8(ra[i][0], ra[i][1], hi, lo);
-            const int off = so + (row * OCT + (a_oct ^ ((row >> SWZ_SHIFT) & SWZ))) * 8;
+            const int off = so + (row * 4 + (a_oct ^ ((row >> 2) & 3))) * 8;
             *reinterpret_cast<f16x8*>(sAh + off) = hi;
             *reinterpret_cast<f16x8*>(sAl + off) = lo;
         }
 #pragma unroll
-        for (int i = 0; i < PER_THREAD; ++i) {
-            const int slot = tid + 256 * i;
+        for (int i = 0; i < PB; ++i) {
+            const int slot = tid + NT * i;
             *reinterpret_cast<f16x8*>(sBh + so + slot * 8) = rbh[i];
             *reinterpret_cast<f16x8*>(sBl + so + slot * 8) = rbl[i];
         }
@@ -387,52 +398,94 @@ __global__ __launch_bounds__(256, MINW) void pw_gemm_f16x3_kernel(PwArgs p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    const int KT = (p.K + BKT - 1) / BKT;
+    const int KT = (p.K + BK - 1) / BK;
+#ifdef ASR_GEMM_PHASE_PROFILE
+    long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long tprev = (long long)__builtin_readcyclecounter();
+#endif
     load_tile(0);
     store_tile(0);
     __syncthreads();
+    PHASE_MARK(0);                                             // prologue: first tile in, LDS filled
     for (int kt = 0; kt < KT; ++kt) {
         const int so = DBUF ? (kt & 1) * STAGE : 0;
+        // All loads of the next tile go out before the MFMAs: a wave stalls ~250 cycles in the vector-memory issue queue
+        // per 1 KiB load while every wave of the CU is loading, and spreading the loads between MFMA groups (tried) only
+        // spreads that stall over the matrix pipe's busy phase (-15 %).
         if (kt + 1 < KT && !(p.debug & 2)) load_tile(kt + 1);
+        PHASE_MARK(1);                                         // global loads issued
 #pragma unroll
-        for (int s = 0; s < BKT / 16; ++s) {
+        for (int s = 0; s < BK / 16; ++s) {
             const int oct = 2 * s + hh;
-            f16x8 ah[TM], al[TM], bh[TN], bl[TN];
+            f16x8 ah[TM], al[TM];
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 const int row = (wm * TM + i) * 32 + l32;
-                const int off = so + (row * OCT + (oct ^ ((row >> SWZ_SHIFT) & SWZ))) * 8;
+                const int off = so + (row * 4 + (oct ^ ((row >> 2) & 3))) * 8;
                 ah[i] = *reinterpret_cast<const f16x8*>(sAh + off);
                 al[i] = *reinterpret_cast<const f16x8*>(sAl + off);
             }
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int col = (wn * TN + j) * 32 + l32;
-                bh[j] = *reinterpret_cast<const f16x8*>(sBh + so + (oct * BN + col) * 8);
-                bl[j] = *reinterpret_cast<const f16x8*>(sBl + so + (oct * BN + col) * 8);
-            }
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
+            if (TN <= 2) {                                 // all fragments first, then a row-major MFMA sweep
+                f16x8 bh[TN], bl[TN];
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                    const int col = (wn * TN + j) * 32 + l32;
+                    bh[j] = *reinterpret_cast<const f16x8*>(sBh + so + (oct * BN + col) * 8);
+                    bl[j] = *reinterpret_cast<const f16x8*>(sBl + so + (oct * BN + col) * 8);
                 }
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                    }
+            } else {                                       // wide wave tile: B fragments one column block at a time
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int col = (wn * TN + j) * 32 + l32;
+                    const f16x8 bh = *reinterpret_cast<const f16x8*>(sBh + so + (oct * BN + col) * 8);
+                    const f16x8 bl = *reinterpret_cast<const f16x8*>(sBl + so + (oct * BN + col) * 8);
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh, acc[i][j], 0, 0, 0);
+                    }
+                }
+            }
         }
+        PHASE_MARK(2);                                         // LDS fragment reads + MFMA issue
         if (kt + 1 < KT) {
             if (DBUF) {
+                PHASE_WAIT_VM();
+                PHASE_MARK(3);                                 // next tile's global loads landed
                 store_tile((kt + 1) & 1);
+                PHASE_WAIT_LGKM();
+                PHASE_MARK(5);                                 // split to f16 + LDS stores (other stage)
                 __syncthreads();
+                PHASE_MARK(6);
             } else {
+                PHASE_WAIT_VM();
+                PHASE_MARK(3);                                 // next tile's global loads landed
                 __syncthreads();
+                PHASE_MARK(4);                                 // every wave done reading the tile
                 store_tile(0);
+                PHASE_WAIT_LGKM();
+                PHASE_MARK(5);                                 // split to f16 + LDS stores
                 __syncthreads();
+                PHASE_MARK(6);                                 // stores of every wave visible
             }
         }
     }
     __syncthreads();
     pw_epilogue<WM, WN, TM, TN>(p, acc, smem, tile_m, tile_n, wave, lane);
+#ifdef ASR_GEMM_PHASE_PROFILE
+    PHASE_MARK(7);                                             // epilogue
+    if (tid == 0 && orig < ASR_PHASE_BLOCKS)
+        for (int i = 0; i < 8; ++i) g_phase_cycles[orig * 8 + i] = ph[i];
+#endif
 }
 
 // w [K][N] f32 -> two half planes [Kpad/8][Npad][8] (hi then lo), zero padded
@@ -614,28 +667,58 @@ extern "C" int asr_pwconv_mfma_f16x3(const float* x, const float* w_packed, cons
         ASR_REQUIRE(m % ((long long)a.h_out * a.w_out) == 0, "asr_pwconv_mfma_f16x3: m is not a whole number of %dx%d maps",
                     a.h_out, a.w_out);
     }
-    a.tiles_n = (int)asr_cdiv(n, 128);
-    const long long nwg = asr_cdiv(m, 128) * a.tiles_n;
-    ASR_REQUIRE(nwg <= 0x7fffffffLL, "asr_pwconv_mfma_f16x3: grid too large");
-    const size_t lds = sizeof(float) * (128 * BK + BK * 128);
+    // Tile shape: 128x128 (4 waves of 64x64, one LDS stage, 3 workgroups per CU) everywhere.  Measured alternatives
+    // (ASR_F16X3_VARIANT, kept for experiments): 2 = 256x256, 8 waves of 64x128, two LDS stages, one workgroup per CU;
+    // 3 = 128x256, 4 waves of 64x128, two workgroups per CU.  Both stage fewer bytes per flop and came out within +-3 % of
+    // 128x128 (and 10-15 % behind it on the 728-channel middle flow): see DESIGN.md "GEMM phase profile".
     static const int dbg = getenv("ASR_GEMM_DEBUG") ? atoi(getenv("ASR_GEMM_DEBUG")) : 0;
-    static const int f16_variant = getenv("ASR_F16X3_VARIANT") ? atoi(getenv("ASR_F16X3_VARIANT")) : 0;
+    static const int variant = getenv("ASR_F16X3_VARIANT") ? atoi(getenv("ASR_F16X3_VARIANT")) : 0;
     a.debug = dbg;
-    if (f16_variant == 1) {
-        hipLaunchKernelGGL((pw_gemm_f16x3_kernel<32, true, 1>), dim3((unsigned)nwg), dim3(256), 2 * lds, asr_stream(stream), a);
-    } else if (f16_variant == 2) {
-        static bool attr_set = false;
-        if (!attr_set) {
-            ASR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pw_gemm_f16x3_kernel<64, false, 1>),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * lds)));
-            attr_set = true;
-        }
-        hipLaunchKernelGGL((pw_gemm_f16x3_kernel<64, false, 1>), dim3((unsigned)nwg), dim3(256), 2 * lds, asr_stream(stream), a);
-    } else if (f16_variant == 3) {
-        hipLaunchKernelGGL((pw_gemm_f16x3_kernel<32, false, 4>), dim3((unsigned)nwg), dim3(256), lds, asr_stream(stream), a);
-    } else {
-        hipLaunchKernelGGL((pw_gemm_f16x3_kernel<32, false, 1>), dim3((unsigned)nwg), dim3(256), lds, asr_stream(stream), a);
+    int shape = variant ? variant : 1;
+    if ((shape == 2 || shape == 3) && a.Npad % 256 != 0) shape = 1;
+    long long nwg = 0;
+#define ASR_F16X3_LAUNCH(WM_, WN_, TM_, TN_, DBUF_, MINW_)                                                                          \
+    do {                                                                                                                 \
+        constexpr int bm = WM_ * TM_ * 32, bn = WN_ * TN_ * 32;                                                          \
+        constexpr size_t lds_stage = (size_t)(DBUF_ ? 2 : 1) * 2 * BK * (bm + bn) * sizeof(_Float16);                    \
+        constexpr size_t lds_epi = (size_t)WM_ * WN_ * 32 * TN_ * 32 * sizeof(float);                                    \
+        constexpr size_t lds = lds_stage > lds_epi ? lds_stage : lds_epi;                                                \
+        a.tiles_n = (int)asr_cdiv(n, bn);                                                                                \
+        nwg = asr_cdiv(m, bm) * a.tiles_n;                                                                               \
+        ASR_REQUIRE(nwg <= 0x7fffffffLL, "asr_pwconv_mfma_f16x3: grid too large");                                       \
+        auto kern = pw_gemm_f16x3_kernel<WM_, WN_, TM_, TN_, DBUF_, MINW_>;                                                    \
+        if (lds > 64 * 1024) {                                                                                           \
+            static bool attr_set = false;                                                                                \
+            if (!attr_set) {                                                                                             \
+                ASR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                   \
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                \
+                attr_set = true;                                                                                         \
+            }                                                                                                            \
+        }                                                                                                                \
+        hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(WM_ * WN_ * 64), lds, asr_stream(stream), a);                 \
+    } while (0)
+    switch (shape) {
+        case 2: ASR_F16X3_LAUNCH(4, 2, 2, 4, true, 2); break;
+        case 3: ASR_F16X3_LAUNCH(2, 2, 2, 4, false, 2); break;
+        default: ASR_F16X3_LAUNCH(2, 2, 2, 2, false, 1); break;
     }
+#undef ASR_F16X3_LAUNCH
     ASR_LAUNCH_CHECK();
+#ifdef ASR_GEMM_PHASE_PROFILE
+    {
+        static long long host[ASR_PHASE_BLOCKS * 8];
+        ASR_HIP_CHECK(hipDeviceSynchronize());
+        ASR_HIP_CHECK(hipMemcpyFromSymbol(host, HIP_SYMBOL(g_phase_cycles), sizeof(host)));
+        const long long nb = nwg < ASR_PHASE_BLOCKS ? nwg : ASR_PHASE_BLOCKS;
+        double mean[8] = {0};
+        for (long long b = 0; b < nb; ++b)
+            for (int i = 0; i < 8; ++i) mean[i] += (double)host[b * 8 + i] / (double)nb;
+        const int kt = (k + 31) / 32;
+        fprintf(stderr, "[phase] M=%lld K=%d N=%d blocks=%lld ksteps=%d | prologue %.0f | per k-step: issue %.0f  lds+mfma %.0f  vmwait %.0f  "
+                        "barrier1 %.0f  split+store %.0f  barrier2 %.0f | epilogue %.0f | block total %.0f cycles\n",
+                (long long)m, k, n, nwg, kt, mean[0], mean[1] / kt, mean[2] / kt, mean[3] / (kt - 1), mean[4] / (kt - 1), mean[5] / (kt - 1),
+                mean[6] / (kt - 1), mean[7], mean[0] + mean[1] + mean[2] + mean[3] + mean[4] + mean[5] + mean[6] + mean[7]);
+    }
+#endif
     return ASR_OK;
 }

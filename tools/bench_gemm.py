@@ -5,7 +5,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from asr_amd import ops
 dev = torch.device("cuda")
-shapes = [(102400, 728, 728, True), (102400, 1536, 2048, False), (102400, 2048, 256, False), (1638400, 256, 256, False),
+shapes = [(102400, 728, 728, True), (102400, 728, 728, False), (409600, 728, 728, True), (204800, 728, 728, True), (102400, 1536, 2048, False), (102400, 2048, 256, False), (1638400, 256, 256, False),
           (6553600, 128, 128, False), (409600, 728, 728, False), (102400, 1024, 1536, False)]
 for m, k, n, res in shapes:
     x = torch.randn(m, k, device=dev)
