@@ -32,6 +32,18 @@ _i64 = C.c_int64
 _fl = C.c_float
 _sz = C.c_size_t
 
+OPT_ADAM, OPT_SGD, OPT_ADAGRAD, OPT_ADADELTA, OPT_ADAMAX = 0, 1, 2, 3, 4
+PRIOR_TV, PRIOR_BTV = 0, 1
+
+
+class SrConfig(C.Structure):
+    """struct asr_sr_config (include/asr_hip.h): update rule + prior of the *_cfg SR entry points."""
+    _fields_ = [("optimizer", C.c_int), ("flag", C.c_int), ("c0", C.c_float), ("c1", C.c_float), ("c2", C.c_float),
+                ("prior", C.c_int), ("btv_alpha", C.c_float), ("btv_shift", C.c_int)]
+
+
+_cfg = C.POINTER(SrConfig)
+
 # name -> (restype, argtypes).  Order and types mirror include/asr_hip.h exactly.
 SIGNATURES = {
     "asr_last_error": (C.c_char_p, []),
@@ -45,6 +57,9 @@ SIGNATURES = {
     "asr_sr_loss_terms_f64": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "asr_sr_solve_workspace_bytes": (_sz, [_i] * 6),
     "asr_sr_solve_f32": (_i, [_vp] * 10 + [_i, _vp, _vp, _sz] + [_i] * 6 + [_fl] * 7 + [_i, _vp]),
+    "asr_sr_backward_cfg_f32": (_i, [_vp] * 10 + [_i] * 6 + [_fl] * 4 + [_cfg, _vp]),
+    "asr_sr_loss_terms_cfg_f64": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _cfg, _vp]),
+    "asr_sr_solve_cfg_f32": (_i, [_vp] * 10 + [_i, _vp, _vp, _sz] + [_i] * 6 + [_fl] * 4 + [_cfg, _vp]),
     "asr_realign_max_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "asr_realign_mean_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "asr_minmax_f32": (_i, [_vp, _vp, _i64, _i, _vp]),

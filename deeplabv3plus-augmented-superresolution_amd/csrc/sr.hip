@@ -114,9 +114,12 @@ __global__ __launch_bounds__(256) void sr_forward_residual_kernel(
 }
 
 // ---- K_bwd --------------------------------------------------------------------------------
-struct AdamArgs {
-    float one_minus_b1, one_minus_b2, eps;
-    int amsgrad;
+// Update rule and prior of one solver step (from asr_sr_config, include/asr_hip.h).
+struct SrStep {
+    int optimizer, flag;      // ASR_OPT_*, amsgrad / nesterov
+    float c0, c1, c2;         // hyper-parameters, meaning per optimizer (asr_hip.h)
+    int prior, btv_shift;     // ASR_PRIOR_*, bilateral-TV window
+    float btv_w[9];           // alpha^k, k = |h| + |v| (float32 pow like tf.pow)
 };
 
 // One axis of the inverse-translate stage for one integer G_R coordinate c (pure translation:
@@ -165,7 +168,7 @@ __global__ __launch_bounds__(256) void sr_backward_adam_kernel(
     const float* __restrict__ inv_rot_tf, const float* __restrict__ inv_trans_tf,
     float* __restrict__ m, float* __restrict__ v, float* __restrict__ vhat,
     const float* __restrict__ alphas /* [batch] for this iteration */, float* __restrict__ grad_out,
-    SrDims d, float two_lambda_df, float lambda_tv, float two_lambda_l2, float lambda_l1, AdamArgs adam) {
+    SrDims d, float two_lambda_df, float lambda_tv, float two_lambda_l2, float lambda_l1, SrStep st) {
     extern __shared__ float contrib[];                     // [n][kBwdPix]
     const int X = blockIdx.x * kBwdPixX + threadIdx.x;
     const int Y = blockIdx.y * kBwdPixY + threadIdx.y;
@@ -259,15 +262,39 @@ __global__ __launch_bounds__(256) void sr_backward_adam_kernel(
     float g_df = 0.0f;
     for (int n = 0; n < d.n; ++n) g_df += contrib[n * kBwdPix + pix];   // fixed order n = 0..N-1
 
-    // priors (superresolution.py:81-98): TV (forward differences, last row/col 0), L2, L1
+    // priors (superresolution.py:81-98): TV (forward differences, last row/col 0) or bilateral TV, L2, L1
     const float* img = x + (int64_t)b * H * W;
     const float xc = img[Y * W + X];
     auto sgn = [](float a) -> float { return (a > 0.0f) ? 1.0f : ((a < 0.0f) ? -1.0f : 0.0f); };
-    const float sy = (Y < H - 1) ? sgn(img[(Y + 1) * W + X] - xc) * lambda_tv : 0.0f;
-    const float sx = (X < W - 1) ? sgn(img[Y * W + X + 1] - xc) * lambda_tv : 0.0f;
-    float g_tv = -sy - sx;
-    if (Y > 0) g_tv += sgn(xc - img[(Y - 1) * W + X]) * lambda_tv;
-    if (X > 0) g_tv += sgn(xc - img[Y * W + X - 1]) * lambda_tv;
+    float g_tv;
+    if (st.prior == ASR_PRIOR_BTV) {
+        // bilateral_tv (superresolution.py:8-23): sum over pairs p = (h, v), h in [-s, s], v in [0, s], of
+        // alpha^(|h|+|v|) * || x - translate(x, p) ||_1 with translate(x, p)(q) = x(q - p), zero outside.
+        // x enters twice: as the minuend (Abs grad = sign) and through the translate, whose registered gradient
+        // samples the upstream at q + p.  Both sums run in the pair order of the reference's list comprehension.
+        const int sh = st.btv_shift;
+        float ga = 0.0f, gb = 0.0f;
+        for (int hh = -sh; hh <= sh; ++hh)
+            for (int vv = 0; vv <= sh; ++vv) {
+                const float c = lambda_tv * st.btv_w[abs(hh) + vv];
+                const int xs = X - hh, ys = Y - vv;
+                const float sv = (xs >= 0 && xs < W && ys >= 0 && ys < H) ? img[ys * W + xs] : 0.0f;
+                ga += sgn(xc - sv) * c;
+            }
+        for (int hh = -sh; hh <= sh; ++hh)
+            for (int vv = 0; vv <= sh; ++vv) {
+                const float c = lambda_tv * st.btv_w[abs(hh) + vv];
+                const int xt = X + hh, yt = Y + vv;
+                if (xt >= 0 && xt < W && yt >= 0 && yt < H) gb -= sgn(img[yt * W + xt] - xc) * c;
+            }
+        g_tv = ga + gb;
+    } else {
+        const float sy = (Y < H - 1) ? sgn(img[(Y + 1) * W + X] - xc) * lambda_tv : 0.0f;
+        const float sx = (X < W - 1) ? sgn(img[Y * W + X + 1] - xc) * lambda_tv : 0.0f;
+        g_tv = -sy - sx;
+        if (Y > 0) g_tv += sgn(xc - img[(Y - 1) * W + X]) * lambda_tv;
+        if (X > 0) g_tv += sgn(xc - img[Y * W + X - 1]) * lambda_tv;
+    }
     float g = g_df + g_tv + two_lambda_l2 * xc;
     if (lambda_l1 > 0.0f) g = g + lambda_l1 * sgn(xc);
 
@@ -275,26 +302,65 @@ __global__ __launch_bounds__(256) void sr_backward_adam_kernel(
     if (grad_out) grad_out[o] = g;
     if (!x_new) return;
 
-    // Keras Adam / AMSGrad (training_ops ApplyAdam[WithAmsgrad])
+    // apply_gradients: the dense CPU kernels of tensorflow/core/kernels/training_ops.cc that Keras 2.7 dispatches to
+    // (operation order as in their Eigen expressions; alpha = the per-step scalar the host prepared)
     const float alpha = alphas[b];
-    float mm = m[o], vv = v[o];
-    mm = mm + (g - mm) * adam.one_minus_b1;
-    vv = vv + (g * g - vv) * adam.one_minus_b2;
-    m[o] = mm;
-    v[o] = vv;
-    float denom;
-    if (adam.amsgrad) {
-        const float vh = fmaxf(vhat[o], vv);
-        vhat[o] = vh;
-        denom = sqrtf(vh) + adam.eps;
-    } else {
-        denom = sqrtf(vv) + adam.eps;
+    switch (st.optimizer) {
+        case ASR_OPT_SGD: {                                 // ApplyGradientDescent / ApplyKerasMomentum
+            if (st.c0 == 0.0f) {
+                x_new[o] = xc - g * alpha;
+            } else {
+                const float acc = m[o] * st.c0 - g * alpha;
+                m[o] = acc;
+                x_new[o] = st.flag ? xc + (acc * st.c0 - g * alpha) : xc + acc;
+            }
+            break;
+        }
+        case ASR_OPT_ADAGRAD: {                             // ApplyAdagradV2
+            const float acc = v[o] + g * g;
+            v[o] = acc;
+            x_new[o] = xc - (g * alpha) / (sqrtf(acc) + st.c2);
+            break;
+        }
+        case ASR_OPT_ADADELTA: {                            // ApplyAdadelta: c0 = rho, c1 = 1 - rho
+            const float acc = v[o] * st.c0 + (g * g) * st.c1;
+            v[o] = acc;
+            const float au = m[o];
+            const float upd = sqrtf(au + st.c2) * (1.0f / sqrtf(acc + st.c2)) * g;
+            x_new[o] = xc - upd * alpha;
+            m[o] = au * st.c0 + (upd * upd) * st.c1;
+            break;
+        }
+        case ASR_OPT_ADAMAX: {                              // ApplyAdaMax: c0 = 1 - beta1, c1 = beta2
+            float mm = m[o];
+            mm = mm + (g - mm) * st.c0;
+            const float vv = fmaxf(st.c1 * v[o], fabsf(g));
+            m[o] = mm;
+            v[o] = vv;
+            x_new[o] = xc - alpha * (mm / (vv + st.c2));
+            break;
+        }
+        default: {                                          // ApplyAdam[WithAmsgrad]: c0 = 1 - beta1, c1 = 1 - beta2
+            float mm = m[o], vv = v[o];
+            mm = mm + (g - mm) * st.c0;
+            vv = vv + (g * g - vv) * st.c1;
+            m[o] = mm;
+            v[o] = vv;
+            float denom;
+            if (st.flag) {
+                const float vh = fmaxf(vhat[o], vv);
+                vhat[o] = vh;
+                denom = sqrtf(vh) + st.c2;
+            } else {
+                denom = sqrtf(vv) + st.c2;
+            }
+            x_new[o] = xc - (mm * alpha) / denom;
+        }
     }
-    x_new[o] = xc - (mm * alpha) / denom;
 }
 
 typedef void (*SrBwdKernel)(const float*, float*, const float*, const float*, const float*, float*, float*, float*,
-                            const float*, float*, SrDims, float, float, float, float, AdamArgs);
+                            const float*, float*, SrDims, float, float, float, float, SrStep);
 
 SrBwdKernel sr_backward_kernel_for(int f) {
     switch (f) {
@@ -320,7 +386,7 @@ __global__ __launch_bounds__(256) void sr_loss_df_kernel(const float* __restrict
 }
 
 __global__ __launch_bounds__(256) void sr_loss_prior_kernel(const float* __restrict__ x, double* __restrict__ out,
-                                                            int H, int W) {
+                                                            int H, int W, SrStep st) {
     const int b = blockIdx.y;
     const float* img = x + (int64_t)b * H * W;
     double tv = 0.0, l2 = 0.0, l1 = 0.0;
@@ -328,9 +394,18 @@ __global__ __launch_bounds__(256) void sr_loss_prior_kernel(const float* __restr
     for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < total; p += (int64_t)gridDim.x * 256) {
         const int X = (int)(p % W), Y = (int)(p / W);
         const float xc = img[p];
-        const float dy = (Y < H - 1) ? img[p + W] - xc : 0.0f;
-        const float dx = (X < W - 1) ? img[p + 1] - xc : 0.0f;
-        tv += (double)(fabsf(dy) + fabsf(dx));
+        if (st.prior == ASR_PRIOR_BTV) {
+            for (int hh = -st.btv_shift; hh <= st.btv_shift; ++hh)
+                for (int vv = 0; vv <= st.btv_shift; ++vv) {
+                    const int xs = X - hh, ys = Y - vv;
+                    const float sv = (xs >= 0 && xs < W && ys >= 0 && ys < H) ? img[(int64_t)ys * W + xs] : 0.0f;
+                    tv += (double)st.btv_w[abs(hh) + vv] * (double)fabsf(xc - sv);
+                }
+        } else {
+            const float dy = (Y < H - 1) ? img[p + W] - xc : 0.0f;
+            const float dx = (X < W - 1) ? img[p + 1] - xc : 0.0f;
+            tv += (double)(fabsf(dy) + fabsf(dx));
+        }
         l2 += (double)(xc * xc);
         l1 += (double)fabsf(xc);
     }
@@ -440,42 +515,100 @@ extern "C" int asr_sr_forward_residual_f32(const float* x, const float* y, const
     return ASR_OK;
 }
 
+namespace {
+
+// asr_sr_config -> kernel argument; validates the host-side choices
+int make_step(const char* fn, const asr_sr_config* cfg, bool need_update, const float* m, const float* v, const float* vhat,
+              SrStep* st) {
+    ASR_REQUIRE(cfg, "%s: null config", fn);
+    ASR_REQUIRE(cfg->optimizer >= ASR_OPT_ADAM && cfg->optimizer <= ASR_OPT_ADAMAX, "%s: unknown optimizer %d", fn, cfg->optimizer);
+    ASR_REQUIRE(cfg->prior == ASR_PRIOR_TV || cfg->prior == ASR_PRIOR_BTV, "%s: unknown prior %d", fn, cfg->prior);
+    st->optimizer = cfg->optimizer; st->flag = cfg->flag; st->c0 = cfg->c0; st->c1 = cfg->c1; st->c2 = cfg->c2;
+    st->prior = cfg->prior; st->btv_shift = 0;
+    for (int k = 0; k < 9; ++k) st->btv_w[k] = 0.0f;
+    if (cfg->prior == ASR_PRIOR_BTV) {
+        ASR_REQUIRE(cfg->btv_shift >= 1 && cfg->btv_shift <= 4, "%s: btv_shift %d outside [1, 4]", fn, cfg->btv_shift);
+        st->btv_shift = cfg->btv_shift;
+        for (int k = 0; k <= 2 * cfg->btv_shift; ++k) st->btv_w[k] = powf(cfg->btv_alpha, (float)k);   // tf.pow in float32
+    }
+    if (need_update) {
+        bool ok = true;
+        switch (cfg->optimizer) {
+            case ASR_OPT_ADAM: ok = m && v && (vhat || !cfg->flag); break;
+            case ASR_OPT_SGD: ok = m || cfg->c0 == 0.0f; break;
+            case ASR_OPT_ADAGRAD: ok = v != nullptr; break;
+            default: ok = m && v; break;
+        }
+        ASR_REQUIRE(ok, "%s: optimizer %d needs slot buffers that were not given", fn, cfg->optimizer);
+    }
+    return ASR_OK;
+}
+
+asr_sr_config adam_tv_config(float one_minus_beta1, float one_minus_beta2, float epsilon, int amsgrad) {
+    asr_sr_config c{};
+    c.optimizer = ASR_OPT_ADAM; c.flag = amsgrad; c.c0 = one_minus_beta1; c.c1 = one_minus_beta2; c.c2 = epsilon;
+    c.prior = ASR_PRIOR_TV;
+    return c;
+}
+
+}  // namespace
+
+extern "C" int asr_sr_backward_cfg_f32(const float* x, float* x_new, const float* resid, const float* inv_rot_tf,
+                                       const float* inv_trans_tf, float* m, float* v, float* vhat, const float* alphas,
+                                       float* grad_out, int batch, int n, int H, int W, int h, int w, float lambda_df,
+                                       float lambda_tv, float lambda_l2, float lambda_l1, const asr_sr_config* cfg,
+                                       asr_stream_t stream) {
+    ASR_REQUIRE(x && resid && inv_rot_tf && inv_trans_tf, "asr_sr_backward_cfg_f32: null pointer");
+    ASR_REQUIRE(x_new || grad_out, "asr_sr_backward_cfg_f32: need x_new and/or grad_out");
+    ASR_REQUIRE(!x_new || alphas, "asr_sr_backward_cfg_f32: alphas required with x_new");
+    ASR_REQUIRE(x != x_new, "asr_sr_backward_cfg_f32: x_new must not alias x (the priors read neighbours)");
+    SrDims d;
+    int rc = check_dims("asr_sr_backward_cfg_f32", batch, n, H, W, h, w, &d);
+    if (rc != ASR_OK) return rc;
+    SrStep st;
+    rc = make_step("asr_sr_backward_cfg_f32", cfg, x_new != nullptr, m, v, vhat, &st);
+    if (rc != ASR_OK) return rc;
+    rc = prepare_backward(d);
+    if (rc != ASR_OK) return rc;
+    hipLaunchKernelGGL(sr_backward_kernel_for(d.f), bwd_grid(d), kBwdBlock, bwd_lds(d), asr_stream(stream), x, x_new, resid, inv_rot_tf,
+                       inv_trans_tf, m, v, vhat, alphas, grad_out, d, 2.0f * lambda_df, lambda_tv, 2.0f * lambda_l2,
+                       lambda_l1, st);
+    ASR_LAUNCH_CHECK();
+    return ASR_OK;
+}
+
 extern "C" int asr_sr_backward_adam_f32(const float* x, float* x_new, const float* resid, const float* inv_rot_tf,
                                         const float* inv_trans_tf, float* m, float* v, float* vhat,
                                         const float* alphas, float* grad_out, int batch, int n, int H, int W, int h,
                                         int w, float lambda_df, float lambda_tv, float lambda_l2, float lambda_l1,
                                         float one_minus_beta1, float one_minus_beta2, float epsilon, int amsgrad,
                                         asr_stream_t stream) {
-    ASR_REQUIRE(x && resid && inv_rot_tf && inv_trans_tf, "asr_sr_backward_adam_f32: null pointer");
-    ASR_REQUIRE(x_new || grad_out, "asr_sr_backward_adam_f32: need x_new and/or grad_out");
-    ASR_REQUIRE(!x_new || (m && v && alphas && (vhat || !amsgrad)),
-                "asr_sr_backward_adam_f32: Adam state (m, v, vhat, alphas) required with x_new");
-    ASR_REQUIRE(x != x_new, "asr_sr_backward_adam_f32: x_new must not alias x (TV reads neighbours)");
-    SrDims d;
-    int rc = check_dims("asr_sr_backward_adam_f32", batch, n, H, W, h, w, &d);
+    const asr_sr_config c = adam_tv_config(one_minus_beta1, one_minus_beta2, epsilon, amsgrad);
+    return asr_sr_backward_cfg_f32(x, x_new, resid, inv_rot_tf, inv_trans_tf, m, v, vhat, alphas, grad_out, batch, n, H, W,
+                                   h, w, lambda_df, lambda_tv, lambda_l2, lambda_l1, &c, stream);
+}
+
+extern "C" int asr_sr_loss_terms_cfg_f64(const float* x, const float* resid, double* terms, int batch, int n, int H, int W,
+                                         int h, int w, const asr_sr_config* cfg, asr_stream_t stream) {
+    ASR_REQUIRE(x && resid && terms, "asr_sr_loss_terms_cfg_f64: null pointer");
+    ASR_REQUIRE(batch > 0 && batch <= 65535, "asr_sr_loss_terms_cfg_f64: bad batch %d", batch);
+    SrStep st;
+    int rc = make_step("asr_sr_loss_terms_cfg_f64", cfg, false, nullptr, nullptr, nullptr, &st);
     if (rc != ASR_OK) return rc;
-    AdamArgs a{one_minus_beta1, one_minus_beta2, epsilon, amsgrad};
-    rc = prepare_backward(d);
-    if (rc != ASR_OK) return rc;
-    hipLaunchKernelGGL(sr_backward_kernel_for(d.f), bwd_grid(d), kBwdBlock, bwd_lds(d), asr_stream(stream), x, x_new, resid, inv_rot_tf,
-                       inv_trans_tf, m, v, vhat, alphas, grad_out, d, 2.0f * lambda_df, lambda_tv, 2.0f * lambda_l2,
-                       lambda_l1, a);
+    hipStream_t s = asr_stream(stream);
+    ASR_HIP_CHECK(hipMemsetAsync(terms, 0, sizeof(double) * 4 * batch, s));
+    const int64_t per_image = (int64_t)n * h * w;
+    hipLaunchKernelGGL(sr_loss_df_kernel, dim3(64, batch), dim3(256), 0, s, resid, terms, per_image);
+    ASR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(sr_loss_prior_kernel, dim3(64, batch), dim3(256), 0, s, x, terms, H, W, st);
     ASR_LAUNCH_CHECK();
     return ASR_OK;
 }
 
 extern "C" int asr_sr_loss_terms_f64(const float* x, const float* resid, double* terms, int batch, int n, int H, int W,
                                      int h, int w, asr_stream_t stream) {
-    ASR_REQUIRE(x && resid && terms, "asr_sr_loss_terms_f64: null pointer");
-    ASR_REQUIRE(batch > 0 && batch <= 65535, "asr_sr_loss_terms_f64: bad batch %d", batch);
-    hipStream_t s = asr_stream(stream);
-    ASR_HIP_CHECK(hipMemsetAsync(terms, 0, sizeof(double) * 4 * batch, s));
-    const int64_t per_image = (int64_t)n * h * w;
-    hipLaunchKernelGGL(sr_loss_df_kernel, dim3(64, batch), dim3(256), 0, s, resid, terms, per_image);
-    ASR_LAUNCH_CHECK();
-    hipLaunchKernelGGL(sr_loss_prior_kernel, dim3(64, batch), dim3(256), 0, s, x, terms, H, W);
-    ASR_LAUNCH_CHECK();
-    return ASR_OK;
+    const asr_sr_config c = adam_tv_config(0.f, 0.f, 0.f, 0);
+    return asr_sr_loss_terms_cfg_f64(x, resid, terms, batch, n, H, W, h, w, &c, stream);
 }
 
 extern "C" size_t asr_sr_solve_workspace_bytes(int batch, int n, int H, int W, int h, int w) {
@@ -484,26 +617,27 @@ extern "C" size_t asr_sr_solve_workspace_bytes(int batch, int n, int H, int W, i
 
 // The whole optimisation loop of augmented_superresolution (superresolution.py:120-135) as one
 // host call: num_iter x {K_fwd, K_bwd}, ping-ponging x between the caller's buffer and the
-// workspace.  alphas[it*batch + b] = lr_it * sqrt(1 - beta2^t) / (1 - beta1^t) for image b at
-// its own global Adam step t (device array, prepared by the host wrapper so that the schedule
-// and the persistent step counter follow optimizer.py exactly).
-extern "C" int asr_sr_solve_f32(float* x, const float* y, const float* rot_tf, const float* trans_tf,
-                                const float* inv_rot_tf, const float* inv_trans_tf, float* m, float* v, float* vhat,
-                                const float* alphas, int num_iter, double* last_loss_terms, void* workspace,
-                                size_t workspace_bytes, int batch, int n, int H, int W, int h, int w,
-                                float lambda_df, float lambda_tv, float lambda_l2, float lambda_l1,
-                                float one_minus_beta1, float one_minus_beta2, float epsilon, int amsgrad,
-                                asr_stream_t stream) {
-    ASR_REQUIRE(x && y && rot_tf && trans_tf && inv_rot_tf && inv_trans_tf && m && v && alphas && workspace,
-                "asr_sr_solve_f32: null pointer");
-    ASR_REQUIRE(vhat || !amsgrad, "asr_sr_solve_f32: vhat required for amsgrad");
-    ASR_REQUIRE(num_iter >= 0, "asr_sr_solve_f32: num_iter < 0");
+// workspace.  alphas[it*batch + b] = the per-step scalar of image b at its own global optimiser
+// step (device array, prepared by the host wrapper so that the schedule and the persistent step
+// counter follow optimizer.py exactly).
+extern "C" int asr_sr_solve_cfg_f32(float* x, const float* y, const float* rot_tf, const float* trans_tf,
+                                    const float* inv_rot_tf, const float* inv_trans_tf, float* m, float* v, float* vhat,
+                                    const float* alphas, int num_iter, double* last_loss_terms, void* workspace,
+                                    size_t workspace_bytes, int batch, int n, int H, int W, int h, int w,
+                                    float lambda_df, float lambda_tv, float lambda_l2, float lambda_l1,
+                                    const asr_sr_config* cfg, asr_stream_t stream) {
+    ASR_REQUIRE(x && y && rot_tf && trans_tf && inv_rot_tf && inv_trans_tf && alphas && workspace,
+                "asr_sr_solve_cfg_f32: null pointer");
+    ASR_REQUIRE(num_iter >= 0, "asr_sr_solve_cfg_f32: num_iter < 0");
     SrDims d;
-    int rc = check_dims("asr_sr_solve_f32", batch, n, H, W, h, w, &d);
+    int rc = check_dims("asr_sr_solve_cfg_f32", batch, n, H, W, h, w, &d);
+    if (rc != ASR_OK) return rc;
+    SrStep st;
+    rc = make_step("asr_sr_solve_cfg_f32", cfg, true, m, v, vhat, &st);
     if (rc != ASR_OK) return rc;
     const size_t need = asr_sr_solve_workspace_bytes(batch, n, H, W, h, w);
     if (workspace_bytes < need) {
-        asr_set_error("asr_sr_solve_f32: workspace %zu < required %zu bytes", workspace_bytes, need);
+        asr_set_error("asr_sr_solve_cfg_f32: workspace %zu < required %zu bytes", workspace_bytes, need);
         return ASR_ERR_WORKSPACE;
     }
     hipStream_t s = asr_stream(stream);
@@ -511,7 +645,6 @@ extern "C" int asr_sr_solve_f32(float* x, const float* y, const float* rot_tf, c
     float* x_alt = resid + (size_t)batch * n * h * w;
     float* cur = x;
     float* nxt = x_alt;
-    AdamArgs a{one_minus_beta1, one_minus_beta2, epsilon, amsgrad};
     rc = prepare_backward(d);
     if (rc != ASR_OK) return rc;
     const SrBwdKernel bwd_kernel = sr_backward_kernel_for(d.f);
@@ -519,17 +652,30 @@ extern "C" int asr_sr_solve_f32(float* x, const float* y, const float* rot_tf, c
         hipLaunchKernelGGL(sr_forward_residual_kernel, lr_grid(d), kBlock, 0, s, cur, y, rot_tf, trans_tf, resid, d);
         ASR_LAUNCH_CHECK();
         if (last_loss_terms && it == num_iter - 1) {
-            rc = asr_sr_loss_terms_f64(cur, resid, last_loss_terms, batch, n, H, W, h, w, stream);
+            rc = asr_sr_loss_terms_cfg_f64(cur, resid, last_loss_terms, batch, n, H, W, h, w, cfg, stream);
             if (rc != ASR_OK) return rc;
         }
         hipLaunchKernelGGL(bwd_kernel, bwd_grid(d), kBwdBlock, bwd_lds(d), s, cur, nxt, resid, inv_rot_tf, inv_trans_tf,
                            m, v, vhat, alphas + (size_t)it * batch, (float*)nullptr, d, 2.0f * lambda_df, lambda_tv,
-                           2.0f * lambda_l2, lambda_l1, a);
+                           2.0f * lambda_l2, lambda_l1, st);
         ASR_LAUNCH_CHECK();
         float* t = cur; cur = nxt; nxt = t;
     }
     if (cur != x) ASR_HIP_CHECK(hipMemcpyAsync(x, cur, sizeof(float) * (size_t)batch * H * W, hipMemcpyDeviceToDevice, s));
     return ASR_OK;
+}
+
+extern "C" int asr_sr_solve_f32(float* x, const float* y, const float* rot_tf, const float* trans_tf,
+                                const float* inv_rot_tf, const float* inv_trans_tf, float* m, float* v, float* vhat,
+                                const float* alphas, int num_iter, double* last_loss_terms, void* workspace,
+                                size_t workspace_bytes, int batch, int n, int H, int W, int h, int w,
+                                float lambda_df, float lambda_tv, float lambda_l2, float lambda_l1,
+                                float one_minus_beta1, float one_minus_beta2, float epsilon, int amsgrad,
+                                asr_stream_t stream) {
+    const asr_sr_config c = adam_tv_config(one_minus_beta1, one_minus_beta2, epsilon, amsgrad);
+    return asr_sr_solve_cfg_f32(x, y, rot_tf, trans_tf, inv_rot_tf, inv_trans_tf, m, v, vhat, alphas, num_iter,
+                                last_loss_terms, workspace, workspace_bytes, batch, n, H, W, h, w, lambda_df, lambda_tv,
+                                lambda_l2, lambda_l1, &c, stream);
 }
 
 static int realign_common(bool is_max, const float* y, float* out, const float* trans_tf, const float* rot_tf,

@@ -97,8 +97,41 @@ def sr_forward_residual(x, y, rot_tf, trans_tf):
     return resid
 
 
+def sr_config(optimizer=_lib.OPT_ADAM, flag=False, c0=0.0, c1=0.0, c2=0.0, use_btv=False, btv_alpha=0.6, btv_shift=2):
+    """asr_sr_config for the *_cfg entry points (meaning of c0..c2 per optimizer: include/asr_hip.h)."""
+    return _lib.SrConfig(int(optimizer), int(bool(flag)), float(c0), float(c1), float(c2),
+                         _lib.PRIOR_BTV if use_btv else _lib.PRIOR_TV, float(btv_alpha), int(btv_shift))
+
+
+def _adam_config(one_minus_beta1, one_minus_beta2, epsilon, amsgrad):
+    return sr_config(_lib.OPT_ADAM, amsgrad, one_minus_beta1, one_minus_beta2, epsilon)
+
+
+def sr_backward(x, resid, inv_rot_tf, inv_trans_tf, lambdas, cfg, state=None, want_grad=False):
+    """One step with the update rule / prior of cfg.  state = dict(m, v, vhat, alphas[B]) (slots the optimizer
+    does not use may be None) or None for the gradient only.  Returns (x_new | None, grad | None)."""
+    b, n, H, W, h, w = _sr_dims(x, resid)
+    _check_tf(inv_rot_tf, b, n, "inv_rot_tf")
+    _check_tf(inv_trans_tf, b, n, "inv_trans_tf")
+    grad = torch.empty_like(x) if (want_grad or state is None) else None
+    x_new = torch.empty_like(x) if state is not None else None
+    st = state or {}
+    if state is not None:
+        for k in ("m", "v", "vhat"):
+            if st.get(k) is not None and st[k].shape != x.shape:
+                raise AsrError(f"state['{k}'] shape mismatch")
+        if st["alphas"].numel() != b:
+            raise AsrError("state['alphas'] must hold one value per image")
+    call("asr_sr_backward_cfg_f32", ptr(x), ptr(x_new, allow_none=True), ptr(resid), ptr(inv_rot_tf),
+         ptr(inv_trans_tf), ptr(st.get("m"), allow_none=True), ptr(st.get("v"), allow_none=True),
+         ptr(st.get("vhat"), allow_none=True), ptr(st.get("alphas"), allow_none=True), ptr(grad, allow_none=True),
+         b, n, H, W, h, w, float(lambdas[0]), float(lambdas[1]), float(lambdas[2]), float(lambdas[3]), C.byref(cfg),
+         stream_ptr())
+    return x_new, grad
+
+
 def sr_backward_adam(x, resid, inv_rot_tf, inv_trans_tf, lambdas, adam=None, want_grad=False):
-    """One step.  lambdas = (df, tv, l2, l1).  adam = dict(m, v, vhat, alphas[B], one_minus_beta1,
+    """One Adam / AMSGrad step with the TV prior.  adam = dict(m, v, vhat, alphas[B], one_minus_beta1,
     one_minus_beta2, epsilon, amsgrad) or None for gradient only.  Returns (x_new | None, grad | None)."""
     b, n, H, W, h, w = _sr_dims(x, resid)
     _check_tf(inv_rot_tf, b, n, "inv_rot_tf")
@@ -121,16 +154,23 @@ def sr_backward_adam(x, resid, inv_rot_tf, inv_trans_tf, lambdas, adam=None, wan
     return x_new, grad
 
 
-def sr_loss_terms(x, resid):
+def sr_loss_terms(x, resid, cfg=None):
+    """[B,4] float64 {sum resid^2, TV or bilateral TV (cfg), sum x^2, sum |x|}."""
     b, n, H, W, h, w = _sr_dims(x, resid)
     terms = torch.empty((b, 4), dtype=torch.float64, device=x.device)
-    call("asr_sr_loss_terms_f64", ptr(x), ptr(resid), ptr(terms, torch.float64), b, n, H, W, h, w, stream_ptr())
+    if cfg is None:
+        call("asr_sr_loss_terms_f64", ptr(x), ptr(resid), ptr(terms, torch.float64), b, n, H, W, h, w, stream_ptr())
+    else:
+        call("asr_sr_loss_terms_cfg_f64", ptr(x), ptr(resid), ptr(terms, torch.float64), b, n, H, W, h, w, C.byref(cfg),
+             stream_ptr())
     return terms
 
 
-def sr_solve(x, y, rot_tf, trans_tf, inv_rot_tf, inv_trans_tf, alphas, lambdas, one_minus_beta1, one_minus_beta2,
-             epsilon, amsgrad, want_loss=True):
-    """Runs alphas.shape[0] iterations in place on x.  alphas [num_iter, B] (device)."""
+def sr_solve(x, y, rot_tf, trans_tf, inv_rot_tf, inv_trans_tf, alphas, lambdas, one_minus_beta1=None, one_minus_beta2=None,
+             epsilon=None, amsgrad=False, want_loss=True, cfg=None, slot_init=None):
+    """Runs alphas.shape[0] iterations in place on x.  alphas [num_iter, B] (device).  Either the Adam
+    hyper-parameters (asr_sr_solve_f32) or cfg (+ slot_init = {"m"/"v"/"vhat": initial value}) for
+    asr_sr_solve_cfg_f32."""
     b, n, H, W, h, w = _sr_dims(x, y)
     for t, name in ((rot_tf, "rot_tf"), (trans_tf, "trans_tf"), (inv_rot_tf, "inv_rot_tf"), (inv_trans_tf, "inv_trans_tf")):
         _check_tf(t, b, n, name)
@@ -140,15 +180,22 @@ def sr_solve(x, y, rot_tf, trans_tf, inv_rot_tf, inv_trans_tf, alphas, lambdas, 
     lib = _lib.load()
     ws_bytes = lib.asr_sr_solve_workspace_bytes(b, n, H, W, h, w)
     ws = torch.empty((ws_bytes + 3) // 4, dtype=f32, device=x.device)
-    m = torch.zeros_like(x)
-    v = torch.zeros_like(x)
-    vhat = torch.zeros_like(x)
+    init = slot_init or {}
+    m = torch.full_like(x, float(init.get("m", 0.0)))
+    v = torch.full_like(x, float(init.get("v", 0.0)))
+    vhat = torch.full_like(x, float(init.get("vhat", 0.0)))
     terms = torch.zeros((b, 4), dtype=torch.float64, device=x.device) if want_loss else None
-    call("asr_sr_solve_f32", ptr(x), ptr(y), ptr(rot_tf), ptr(trans_tf), ptr(inv_rot_tf), ptr(inv_trans_tf), ptr(m),
-         ptr(v), ptr(vhat), ptr(alphas), num_iter, ptr(terms, torch.float64, allow_none=True), ptr(ws),
-         C.c_size_t(ws_bytes), b, n, H, W, h, w, float(lambdas[0]), float(lambdas[1]), float(lambdas[2]),
-         float(lambdas[3]), float(one_minus_beta1), float(one_minus_beta2), float(epsilon), int(bool(amsgrad)),
-         stream_ptr())
+    if cfg is None:
+        call("asr_sr_solve_f32", ptr(x), ptr(y), ptr(rot_tf), ptr(trans_tf), ptr(inv_rot_tf), ptr(inv_trans_tf), ptr(m),
+             ptr(v), ptr(vhat), ptr(alphas), num_iter, ptr(terms, torch.float64, allow_none=True), ptr(ws),
+             C.c_size_t(ws_bytes), b, n, H, W, h, w, float(lambdas[0]), float(lambdas[1]), float(lambdas[2]),
+             float(lambdas[3]), float(one_minus_beta1), float(one_minus_beta2), float(epsilon), int(bool(amsgrad)),
+             stream_ptr())
+    else:
+        call("asr_sr_solve_cfg_f32", ptr(x), ptr(y), ptr(rot_tf), ptr(trans_tf), ptr(inv_rot_tf), ptr(inv_trans_tf), ptr(m),
+             ptr(v), ptr(vhat), ptr(alphas), num_iter, ptr(terms, torch.float64, allow_none=True), ptr(ws),
+             C.c_size_t(ws_bytes), b, n, H, W, h, w, float(lambdas[0]), float(lambdas[1]), float(lambdas[2]),
+             float(lambdas[3]), C.byref(cfg), stream_ptr())
     return x, terms
 
 

@@ -3,8 +3,11 @@
 -- plus batched variants that solve many images in one sequence of launches.  All arithmetic
 runs in the fused HIP kernels of csrc/sr.hip; this class only prepares float32 parameters.
 
-``use_BTV`` and ``copy_dropout`` (default off in every shipped configuration) are rejected:
-SURVEY 8f item 3.
+``use_BTV`` swaps the TV prior for the bilateral TV of superresolution.py:8-23 (inside the same
+kernels); ``copy_dropout`` drops a fixed random subset of the copies from the data term: the
+reference draws the mask with np.random.shuffle inside a @tf.function (superresolution.py:44-53),
+i.e. ONCE, when the function is traced on the first solve of a Superresolution object, and every
+later iteration and image reuses it -- ``_drop_mask`` restates exactly that.
 """
 from __future__ import annotations
 
@@ -38,10 +41,6 @@ class Superresolution:
     def __init__(self, lambda_df, lambda_tv, lambda_L2, lambda_L1, num_iter=200, num_aug=100,
                  optimizer: Optimizer = None, feature_size=(64, 64), output_size=(512, 512), use_BTV=False,
                  verbose=False, copy_dropout=0.0):
-        if use_BTV:
-            raise NotImplementedError("bilateral TV (superresolution.py:8-23) is not on the accelerated path")
-        if copy_dropout:
-            raise NotImplementedError("copy_dropout (superresolution.py:47-53) is not on the accelerated path")
         self.lambda_df = lambda_df
         self.lambda_tv = lambda_tv
         self.lambda_L2 = lambda_L2
@@ -54,6 +53,7 @@ class Superresolution:
         self.use_BTV = use_BTV
         self.verbose = verbose
         self.copy_dropout = copy_dropout
+        self._drop_masks = {}        # n_drop -> bool [num_aug], frozen at first use (tf.function trace time)
 
     # -- parameter preparation ----------------------------------------------------------------
     @property
@@ -74,6 +74,21 @@ class Superresolution:
             rot, tr = T.inverse_transforms(rot), T.inverse_transforms(tr)
         return ops.to_device(rot.reshape(b, n, 8), device=device), ops.to_device(tr.reshape(b, n, 8), device=device)
 
+    def _drop_mask(self, n_drop):
+        """superresolution.py:47-50; np.random.shuffle consumes the global numpy stream once per (object, n_drop)."""
+        if n_drop not in self._drop_masks:
+            mask = np.full(self.num_aug, fill_value=True)
+            mask[:n_drop] = False
+            np.random.shuffle(mask)
+            self._drop_masks[n_drop] = mask
+        return self._drop_masks[n_drop]
+
+    def _config(self):
+        """asr_sr_config of this solver: the optimizer's update rule + the TV / bilateral-TV choice."""
+        if self.optimizer is None:
+            return ops.sr_config(use_btv=self.use_BTV)
+        return self.optimizer.optimizer.config(use_btv=self.use_BTV)
+
     @staticmethod
     def _batchify(angles, shifts):
         a = np.asarray(angles, dtype=np.float32)
@@ -82,16 +97,17 @@ class Superresolution:
 
     # -- superresolution.py:44-100 ------------------------------------------------------------------
     def loss_function(self, target_image, augmented_samples, angles, shifts, n_drop=0):
-        if n_drop != 0:
-            raise NotImplementedError("copy dropout is not on the accelerated path")
         dev = _lib.require_gpu()
         y = _stack_copies(augmented_samples, dev)[None]
+        a, s = self._batchify(angles, shifts)
+        if n_drop != 0:
+            keep = torch.as_tensor(self._drop_mask(n_drop), device=dev)
+            y, a, s = y[:, keep].contiguous(), a[:, self._drop_mask(n_drop)], s[:, self._drop_mask(n_drop)]
         x = torch.as_tensor(np.asarray(target_image.cpu() if isinstance(target_image, torch.Tensor) else target_image,
                                        dtype=np.float32)).to(dev).reshape(1, *self.output_size).contiguous()
-        a, s = self._batchify(angles, shifts)
         rot, tr = self._transforms(a, s, dev)
         resid = ops.sr_forward_residual(x, y, rot, tr)
-        return self._loss_from_terms(ops.sr_loss_terms(x, resid).cpu().numpy()[0])
+        return self._loss_from_terms(ops.sr_loss_terms(x, resid, self._config()).cpu().numpy()[0])
 
     def _loss_from_terms(self, t):
         f = np.float32
@@ -112,16 +128,22 @@ class Superresolution:
         b, n, h, w = copies.shape
         if (h, w) != self.feature_size:
             raise ValueError(f"copies are {h}x{w} but feature_size is {self.feature_size}")
+        x = ops.sr_init_target(copies, self.output_size)          # from copy 0 of the FULL stack (superresolution.py:112-114)
+        n_drop = int(self.num_aug * self.copy_dropout)
+        if n_drop != 0:
+            if n != self.num_aug:
+                raise ValueError(f"copy_dropout needs num_aug={self.num_aug} copies per image, got {n}")
+            mask = self._drop_mask(n_drop)
+            copies = copies[:, torch.as_tensor(mask, device=dev)].contiguous()
+            angles, shifts = np.asarray(angles)[:, mask], np.asarray(shifts)[:, mask]
         rot, tr = self._transforms(angles, shifts, dev)
         irot, itr = self._transforms(angles, shifts, dev, inverse=True)
         alphas = np.stack([self.optimizer.schedule_alphas(self.num_iter) for _ in range(b)], axis=1)  # [iter, B]
-        adam = self.optimizer.optimizer
-        x = ops.sr_init_target(copies, self.output_size)
         if self.num_iter == 0:
             return x, [None] * b
-        one = np.float32(1.0)
+        state = self.optimizer.optimizer
         x, terms = ops.sr_solve(x, copies, rot, tr, irot, itr, ops.to_device(alphas, device=dev), self._lambdas,
-                                one - adam.beta_1, one - adam.beta_2, adam.epsilon, adam.amsgrad, want_loss=True)
+                                want_loss=True, cfg=state.config(use_btv=self.use_BTV), slot_init=state.slot_init)
         return x, terms
 
     def augmented_superresolution(self, augmented_copies, angles, shifts):

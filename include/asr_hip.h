@@ -107,6 +107,55 @@ int asr_sr_solve_f32(float* x, const float* y, const float* rot_tf, const float*
                      int h, int w, float lambda_df, float lambda_tv, float lambda_l2, float lambda_l1,
                      float one_minus_beta1, float one_minus_beta2, float epsilon, int amsgrad, asr_stream_t stream);
 
+/* --- the other optimisers and priors of the reference's sweeps -----------------------------------------------
+ * optimizer.py:21-41 lets sweep_all.yaml pick Adadelta / Adagrad / Adamax / SGD besides Adam, and
+ * superresolution.py:8-23,81-82 swaps the TV prior for bilateral TV (use_BTV).  asr_sr_config selects them for
+ * the *_cfg entry points below; the *_adam_f32 / asr_sr_solve_f32 / asr_sr_loss_terms_f64 functions above are the
+ * {ASR_OPT_ADAM, ASR_PRIOR_TV} case.  Update rules are the dense CPU kernels of tensorflow 2.7
+ * (core/kernels/training_ops.cc) that the Keras optimisers dispatch to; `alphas` carries the per-step scalar:
+ *
+ *   optimizer          slots used (zero-initialised unless noted)      c0          c1          c2        alphas[it,b]
+ *   ASR_OPT_ADAM       m, v, vhat (flag = amsgrad)                     1 - beta1   1 - beta2   epsilon   lr_t sqrt(1-beta2^t)/(1-beta1^t)
+ *   ASR_OPT_SGD        m = momentum accumulator (flag = nesterov)      momentum    -           -         lr_t
+ *   ASR_OPT_ADAGRAD    v = accumulator (init initial_accumulator_value) -          -           epsilon   lr_t
+ *   ASR_OPT_ADADELTA   v = accum, m = accum_update                     rho         1 - rho     epsilon   lr_t
+ *   ASR_OPT_ADAMAX     m, v                                            1 - beta1   beta2       epsilon   lr_t / (1 - beta1^t)
+ */
+#define ASR_OPT_ADAM 0
+#define ASR_OPT_SGD 1
+#define ASR_OPT_ADAGRAD 2
+#define ASR_OPT_ADADELTA 3
+#define ASR_OPT_ADAMAX 4
+#define ASR_PRIOR_TV 0
+#define ASR_PRIOR_BTV 1
+
+typedef struct asr_sr_config {
+    int optimizer;     /* ASR_OPT_* */
+    int flag;          /* Adam: amsgrad; SGD: nesterov */
+    float c0, c1, c2;  /* see the table above */
+    int prior;         /* ASR_PRIOR_TV: tf.image.image_gradients TV; ASR_PRIOR_BTV: bilateral_tv */
+    float btv_alpha;   /* bilateral_tv(alpha=0.6, ...) */
+    int btv_shift;     /* bilateral_tv(shift_factor=2): pairs (h, v), h in [-s, s], v in [0, s]; 1 <= s <= 4 */
+} asr_sr_config;
+
+/* asr_sr_backward_adam_f32 with the update rule and prior of `cfg` (host pointer, read during the call). */
+int asr_sr_backward_cfg_f32(const float* x, float* x_new, const float* resid, const float* inv_rot_tf,
+                            const float* inv_trans_tf, float* m, float* v, float* vhat, const float* alphas,
+                            float* grad_out, int batch, int n, int H, int W, int h, int w, float lambda_df,
+                            float lambda_tv, float lambda_l2, float lambda_l1, const asr_sr_config* cfg,
+                            asr_stream_t stream);
+
+/* asr_sr_loss_terms_f64 with terms[b][1] = the prior selected by cfg (TV or bilateral TV). */
+int asr_sr_loss_terms_cfg_f64(const float* x, const float* resid, double* terms, int batch, int n, int H, int W,
+                              int h, int w, const asr_sr_config* cfg, asr_stream_t stream);
+
+/* asr_sr_solve_f32 with the update rule and prior of `cfg`. */
+int asr_sr_solve_cfg_f32(float* x, const float* y, const float* rot_tf, const float* trans_tf, const float* inv_rot_tf,
+                         const float* inv_trans_tf, float* m, float* v, float* vhat, const float* alphas, int num_iter,
+                         double* last_loss_terms, void* workspace, size_t workspace_bytes, int batch, int n, int H, int W,
+                         int h, int w, float lambda_df, float lambda_tv, float lambda_l2, float lambda_l1,
+                         const asr_sr_config* cfg, asr_stream_t stream);
+
 /* out[b] = max / mean over copies of rotate(translate(resize(y[b,i], (H,W)), trans_tf), rot_tf)
  * -- max_superresolution / mean_superresolution, superresolution.py:139-161 (trans_tf built
  * from -shifts, rot_tf from -angles).  out [batch,H,W]. */

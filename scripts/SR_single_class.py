@@ -6,8 +6,6 @@ import argparse
 import os
 import sys
 
-import numpy as np
-
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
@@ -31,10 +29,10 @@ def main():
 
     import torch
     from asr_amd import distributed as D
-    from asr_amd.utils import load_image, compute_IoU
+    from asr_amd.evaluation import evaluate_precomputed
     from asr_amd.superresolution_scripts.optimizer import Optimizer
     from asr_amd.superresolution_scripts.superresolution import Superresolution
-    from asr_amd.superresolution_scripts.superres_utils import list_precomputed_data_paths, load_SR_data, compute_SR
+    from asr_amd.superresolution_scripts.superres_utils import list_precomputed_data_paths
 
     rank, world, local_rank = D.init_from_env()
     torch.cuda.set_device(local_rank)
@@ -45,33 +43,8 @@ def main():
                          lambda_L1=HYPER["lambda_L1"], num_iter=HYPER["num_iter"], num_aug=args.num_aug,
                          optimizer=optimizer_obj, feature_size=FEATURE_SIZE)
     paths = list_precomputed_data_paths(args.data, sort=False)[:args.num_samples]
-    mine = D.shard_indices(len(paths), rank, world)
-    records = []
-    for g in mine:
-        try:
-            class_masks, max_masks, angles, shifts, filename = load_SR_data(paths[g], num_aug=args.num_aug)
-        except Exception:
-            print(f"File: {paths[g]} is invalid, skipping...")
-            records.append([np.nan] * 6)
-            continue
-        mode_solves = 2 if max_masks is not None else 1
-        optimizer_obj.optimizer.iterations = g * HYPER["num_iter"] * mode_solves     # the reference's persistent counter
-        true_mask = load_image(os.path.join(args.gt, f"{filename}.png"), image_size=IMG_SIZE, normalize=False,
-                               is_png=True, resize_method="nearest")
-        mm = max_masks if max_masks is not None else []
-        out = {t: compute_SR(sr, class_masks, angles, shifts, filename, max_masks=mm, SR_type=t, class_id=args.class_id,
-                             dest_folder=args.out, th_factor=args.th_factor) for t in ("aug", "max", "mean")}
-        std = [np.nan, np.nan]
-        if args.standard:
-            sm = load_image(os.path.join(args.standard, f"{filename}.png"), image_size=IMG_SIZE, normalize=False,
-                            is_png=True, resize_method="nearest")
-            std = [compute_IoU(true_mask, sm, img_size=IMG_SIZE, class_id=args.class_id),
-                   compute_IoU(true_mask, sm, img_size=IMG_SIZE, class_id=args.class_id, include_bg=True)]
-        records.append(std + [compute_IoU(true_mask, out["aug"], img_size=IMG_SIZE, class_id=args.class_id),
-                              compute_IoU(true_mask, out["aug"], img_size=IMG_SIZE, class_id=args.class_id, include_bg=True),
-                              compute_IoU(true_mask, out["max"], img_size=IMG_SIZE, class_id=args.class_id),
-                              compute_IoU(true_mask, out["mean"], img_size=IMG_SIZE, class_id=args.class_id)])
-    table = D.all_gather_iou(mine, records, len(paths))
+    table = evaluate_precomputed(sr, paths, args.gt, args.standard, num_aug=args.num_aug, class_id=args.class_id,
+                                 th_factor=args.th_factor, img_size=IMG_SIZE, out_dir=args.out, rank=rank, world=world)
     if rank == 0:
         m = D.mean_ious(table)
         print(f"Avg. Standard IoUs (No bg): {m['standard_single']},  Avg. Augmented SR IoUs (No bg): {m['aug_single']}")

@@ -40,6 +40,16 @@ def test_two_stage_scripts(dev, golden_dir, tmp_path):
                 "--standard", str(std_dir), "--num_aug", "4", "--class_id", "8", "--out", str(tmp_path / "sr_out")],
                str(tmp_path))
     assert "Avg. Max SR IoUs" in out and "Avg. Augmented SR IoUs" in out and "Avg. Standard IoUs (No bg): nan" not in out
+    # one sweep trial (sweep_script.py) with the sweep-only options: Adagrad + bilateral TV + copy dropout
+    import json
+    out = _run([os.path.join(ROOT, "scripts", "sweep_script.py"), "--data", str(data_dir), "--gt", str(gts),
+                "--standard", str(std_dir), "--out", str(tmp_path / "sweep_out"), "--set", "optimizer=adagrad",
+                "--set", "learning_rate=0.01", "--set", "use_BTV=true", "--set", "copy_dropout=0.25", "--set", "num_aug=4",
+                "--set", "num_iter=12"], str(tmp_path))
+    rec = json.loads(out.strip().splitlines()[-1])
+    assert set(rec) == {"aug_iou_single", "aug_iou_multiple", "standard_iou_single", "standard_iou_multiple", "mean_iou",
+                        "max_iou", "config"}
+    assert rec["config"]["optimizer"] == "adagrad" and 0.0 <= rec["aug_iou_single"] <= 1.0
 
 
 def test_single_image_demo(dev, tmp_path):

@@ -41,9 +41,18 @@ def test_optimizer_schedule_and_persistent_counter():
     assert opt.optimizer.iterations == 5
     assert abs(a2[0] - T.adam_alpha(1e-3, 0.9, 0.999, 4)) < 1e-12
     assert float(T.exponential_decay_lr(1e-3, 60, 0.3, 60)) == pytest.approx(3e-4, rel=1e-6)
-    for name in ("adadelta", "adagrad", "adamax", "sgd"):
-        with pytest.raises(NotImplementedError):
-            Optimizer(name)
+    # the sweep-only optimisers (optimizer.py:21-35): per-step scalar and kernel configuration
+    from asr_amd import _lib
+    for name, kind in (("adadelta", _lib.OPT_ADADELTA), ("adagrad", _lib.OPT_ADAGRAD), ("adamax", _lib.OPT_ADAMAX),
+                       ("sgd", _lib.OPT_SGD)):
+        o = Optimizer(name, 1e-2, momentum=0.9, nesterov=True)
+        assert o.optimizer.config(use_btv=True).optimizer == kind and o.optimizer.config(use_btv=True).prior == _lib.PRIOR_BTV
+        a = o.schedule_alphas(2)
+        exp = [1e-2 / (1 - 0.9), 1e-2 / (1 - 0.81)] if name == "adamax" else [1e-2, 1e-2]
+        np.testing.assert_allclose(a, exp, rtol=1e-6)
+    assert Optimizer("adagrad", initial_accumulator_value=0.25).optimizer.slot_init == {"v": 0.25}
+    sgd = Optimizer("sgd", momentum=0.5, nesterov=True).optimizer.config()
+    assert (sgd.flag, sgd.c0) == (1, 0.5)
     assert Optimizer("whatever").optimizer.amsgrad is False     # unknown names fall through to Adam, like the reference
 
 
@@ -67,10 +76,13 @@ def test_sr_object_surface_and_errors():
     from asr_amd.superresolution_scripts.augmentation_utils import create_augmented_copies_chunked
     s = Superresolution(1, 0.3, 0.7, 0.0)
     assert (s.num_iter, s.num_aug, s.feature_size, s.output_size, s.optimizer) == (200, 100, (64, 64), (512, 512), None)
-    with pytest.raises(NotImplementedError):
-        Superresolution(1, 0, 0, 0, use_BTV=True)
-    with pytest.raises(NotImplementedError):
-        Superresolution(1, 0, 0, 0, copy_dropout=0.1)
+    from asr_amd import _lib
+    b = Superresolution(1, 0, 0, 0, num_aug=10, use_BTV=True, copy_dropout=0.25)
+    cfg = b._config()
+    assert (cfg.prior, cfg.btv_shift, round(cfg.btv_alpha, 6)) == (_lib.PRIOR_BTV, 2, 0.6)     # bilateral_tv defaults
+    np.random.seed(3)
+    m = b._drop_mask(int(10 * 0.25))
+    assert m.sum() == 8 and b._drop_mask(2) is m                # superresolution.py:47-50, frozen after the first draw
     with pytest.raises(Exception, match="multiple"):          # augmentation_utils.py:31-32, raised before any GPU work
         create_augmented_copies_chunked(np.zeros((8, 8, 3), np.float32), 150, 0.1, 3, chunk_size=100)
 

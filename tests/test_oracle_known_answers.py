@@ -204,3 +204,60 @@ def test_oracle_model_runs_and_param_inventory():
     assert np.isfinite(out).all() and 0.05 < out.std() < 5
     n_conv = sum(1 for k, *_ in W.layer_inventory() if k in ("conv", "dw"))
     assert n_conv == 2 + 21 * 6 + 4 + 9 + 5 + 1 == 147                  # 147 conv layers
+
+
+def test_other_keras_optimizers_first_steps():
+    """optimizer.py:21-35 -- hand-computed steps of the TF 2.7 dense kernels (SGD / momentum / Nesterov,
+    AdagradV2, Adadelta, AdaMax) on var = 1, grad = 0.5."""
+    def run(kind, steps, **kw):
+        opt = o_sr.Optimizer(kind, 0.1, **kw).optimizer
+        var, grad = torch.ones(1, 2, 2, 1), torch.full((1, 2, 2, 1), 0.5)
+        slots = opt.new_slots(var)
+        for _ in range(steps):
+            opt.apply(var, grad, slots)
+        assert opt.iterations == steps
+        return float(var[0, 0, 0, 0])
+    assert abs(run("sgd", 1) - 0.95) < 1e-7
+    assert abs(run("sgd", 2, momentum=0.9) - 0.855) < 1e-6           # accum: -0.05, -0.095
+    assert abs(run("sgd", 1, momentum=0.9, nesterov=True) - 0.905) < 1e-6
+    assert abs(run("adagrad", 1) - (1 - 0.05 / (np.sqrt(0.35) + 1e-7))) < 1e-6    # accum 0.1 + 0.25
+    upd = np.sqrt(1e-7) / np.sqrt(0.05 * 0.25 + 1e-7) * 0.5
+    assert abs(run("adadelta", 1) - (1 - 0.1 * upd)) < 1e-7
+    assert abs(run("adamax", 1) - 0.9) < 1e-6                         # lr/(1-b1) * (0.05 / 0.5)
+    # any other name falls through to Adam (optimizer.py:36-41)
+    assert isinstance(o_sr.Optimizer("rmsprop").optimizer, o_sr.KerasAdam)
+
+
+def test_bilateral_tv_value_and_gradient():
+    """superresolution.py:8-23: 15 (h, v) pairs weighted 0.6^(|h|+|v|); gradient vs autograd of the same sum."""
+    assert len(o_sr.btv_pairs()) == 15 and o_sr.btv_pairs()[0] == (-2, 0) and o_sr.btv_pairs()[-1] == (2, 2)
+    const = torch.ones(1, 8, 8, 1)
+    # a constant image only differs from its zero-filled translates on the uncovered border strips
+    exp = sum(float(o_sr.btv_weight(0.6, h, v)) * (64 - (8 - abs(h)) * (8 - v)) for h, v in o_sr.btv_pairs())
+    assert abs(o_sr.bilateral_tv(const) - exp) < 1e-4
+    torch.manual_seed(0)
+    x = torch.rand(1, 7, 6, 1)
+    xd = x.double().requires_grad_(True)
+    tot = 0
+    for h, v in o_sr.btv_pairs():
+        sh = torch.zeros_like(xd)
+        sh[0, max(v, 0):, max(h, 0):7 if h >= 0 else 6 + h, 0] = xd[0, :7 - v, max(-h, 0):6 - max(h, 0), 0]
+        tot = tot + float(o_sr.btv_weight(0.6, h, v)) * (xd - sh).abs().sum()
+    tot.backward()
+    g = o_sr.bilateral_tv_grad(x, 0.3)
+    np.testing.assert_allclose(g.numpy(), 0.3 * xd.grad.numpy(), rtol=0, atol=2e-6)
+
+
+def test_copy_dropout_mask_is_drawn_once():
+    """superresolution.py:47-53 runs np.random.shuffle inside a @tf.function: once per object (trace time)."""
+    sr = o_sr.Superresolution(1, 0, 0, 0, num_aug=10, copy_dropout=0.3)
+    np.random.seed(5)
+    exp = np.full(10, True)
+    exp[:3] = False
+    np.random.shuffle(exp)
+    np.random.seed(5)
+    m1 = sr.drop_mask(3).copy()
+    state = np.random.get_state()[1].copy()
+    m2 = sr.drop_mask(3)
+    assert np.array_equal(m1, exp) and np.array_equal(m1, m2) and m1.sum() == 7
+    assert np.array_equal(state, np.random.get_state()[1])       # no further draws
