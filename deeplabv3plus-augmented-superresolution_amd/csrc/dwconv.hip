@@ -131,15 +131,21 @@ __global__ __launch_bounds__(256) void dw_stream_kernel(DwArgs p, int tiles_x) {
             if (vl) l = *reinterpret_cast<const f32x4*>(row + (long long)ixl * p.ldx);
             if (vc) c = *reinterpret_cast<const f32x4*>(row + (long long)ixc * p.ldx);
             if (vr) r = *reinterpret_cast<const f32x4*>(row + (long long)ixr * p.ldx);
-            if (p.pre_relu) { l = relu4(l); c = relu4(c); r = relu4(r); }
         }
     };
+    // The pre-activation is applied when a row ENTERS the window, not when it is loaded: touching the registers of a
+    // load right after issuing it makes the compiler wait for it there (s_waitcnt vmcnt(0)) and the "prefetch" of the
+    // next rows would be synchronous on every pre-ReLU layer (all of the middle flow).
+    auto act = [&](const f32x4& v) { return p.pre_relu ? relu4(v) : v; };
 
     // window rows [base, base + WIN) with base = oy * S - pad_top; it advances by S rows per output row
     f32x4 win[WIN][3], nxt[S][3];
     const int base0 = oy0 * S - p.pad_top;
 #pragma unroll
-    for (int k = 0; k < WIN - S; ++k) load_row(base0 + k, win[S + k][0], win[S + k][1], win[S + k][2]);
+    for (int k = 0; k < WIN - S; ++k) {
+        load_row(base0 + k, win[S + k][0], win[S + k][1], win[S + k][2]);
+        win[S + k][0] = act(win[S + k][0]); win[S + k][1] = act(win[S + k][1]); win[S + k][2] = act(win[S + k][2]);
+    }
 #pragma unroll
     for (int j = 0; j < S; ++j) load_row(base0 + WIN - S + j, nxt[j][0], nxt[j][1], nxt[j][2]);
     const int rows = min(SROWS, p.h_out - oy0);
@@ -147,7 +153,7 @@ __global__ __launch_bounds__(256) void dw_stream_kernel(DwArgs p, int tiles_x) {
 #pragma unroll
         for (int k = 0; k < WIN - S; ++k) { win[k][0] = win[k + S][0]; win[k][1] = win[k + S][1]; win[k][2] = win[k + S][2]; }
 #pragma unroll
-        for (int j = 0; j < S; ++j) { win[WIN - S + j][0] = nxt[j][0]; win[WIN - S + j][1] = nxt[j][1]; win[WIN - S + j][2] = nxt[j][2]; }
+        for (int j = 0; j < S; ++j) { win[WIN - S + j][0] = act(nxt[j][0]); win[WIN - S + j][1] = act(nxt[j][1]); win[WIN - S + j][2] = act(nxt[j][2]); }
         if (r + 1 < rows) {  // prefetch the S input rows the next output row adds
 #pragma unroll
             for (int j = 0; j < S; ++j) load_row(base0 + r * S + WIN + j, nxt[j][0], nxt[j][1], nxt[j][2]);
@@ -159,6 +165,84 @@ __global__ __launch_bounds__(256) void dw_stream_kernel(DwArgs p, int tiles_x) {
             for (int kx = 0; kx < 3; ++kx) acc += win[ky * R][kx] * wk[ky * 3 + kx];
         if (p.post_relu) acc = relu4(acc);
         *reinterpret_cast<f32x4*>(yout + ((long long)(oy0 + r) * p.w_out + ox) * p.ldy) = acc;
+    }
+}
+
+// The same register window for strips that are all full (h_out % SROWS == 0: every layer of the net), written so that
+// the compiler can count outstanding memory operations exactly: no branch around any load or store (rows and columns
+// outside the image are CLAMPED to a valid address and zeroed when the row enters the window), PF output rows of
+// input in flight per thread, held in a queue indexed at compile time (the strip loop is unrolled PF-fold, no register
+// of an outstanding load is ever copied).  s_waitcnt vmcnt(N) then waits for exactly the row that enters the window
+// and leaves the younger loads and the previous stores in flight; with a branch or a copy in the way the wait
+// degenerates to vmcnt(0) and every "prefetch" is synchronous.
+template <int R, int S, int SROWS, int PF>
+__global__ __launch_bounds__(256) void dw_stream_full_kernel(DwArgs p, int tiles_x) {
+    constexpr int WIN = 2 * R + 1;
+    static_assert(SROWS % PF == 0, "strip length must be a multiple of the prefetch depth");
+    const int tid = threadIdx.x;
+    const int c4 = tid & 15, col = tid >> 4;
+    const int tx = blockIdx.x % tiles_x, cbk = blockIdx.x / tiles_x;
+    const int ch = (cbk * 16 + c4) * 4;
+    const int ox = tx * SCOLS + col;
+    const int oy0 = blockIdx.y * SROWS;
+    const int b = blockIdx.z;
+    if (ch >= p.c || ox >= p.w_out) return;
+    const float* xin = p.x + (long long)b * p.h_in * p.w_in * p.ldx + ch;
+    float* yout = p.y + ((long long)b * p.h_out * p.w_out + ox) * p.ldy + ch;
+    f32x4 wk[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) wk[t] = *reinterpret_cast<const f32x4*>(p.w + (long long)t * p.c + ch);
+    const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + ch);
+    const int ixl = ox * S - p.pad_left, ixc = ixl + R, ixr = ixl + 2 * R;
+    const bool vl = ixl >= 0 && ixl < p.w_in, vc = ixc >= 0 && ixc < p.w_in, vr = ixr >= 0 && ixr < p.w_in;
+    const long long ofl = (long long)min(max(ixl, 0), p.w_in - 1) * p.ldx, ofc = (long long)min(max(ixc, 0), p.w_in - 1) * p.ldx,
+                    ofr = (long long)min(max(ixr, 0), p.w_in - 1) * p.ldx;
+    const long long row_stride = (long long)p.w_in * p.ldx;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+
+    auto issue = [&](int iy, f32x4 (&d)[3]) {                 // three unconditional loads from a clamped row
+        const float* row = xin + (long long)min(max(iy, 0), p.h_in - 1) * row_stride;
+        d[0] = *reinterpret_cast<const f32x4*>(row + ofl);
+        d[1] = *reinterpret_cast<const f32x4*>(row + ofc);
+        d[2] = *reinterpret_cast<const f32x4*>(row + ofr);
+    };
+    auto enter = [&](int iy, const f32x4 (&d)[3], f32x4 (&w)[3]) {   // zero padding + pre-activation at window entry
+        const bool vy = iy >= 0 && iy < p.h_in;
+        w[0] = (vy && vl) ? (p.pre_relu ? relu4(d[0]) : d[0]) : zero;
+        w[1] = (vy && vc) ? (p.pre_relu ? relu4(d[1]) : d[1]) : zero;
+        w[2] = (vy && vr) ? (p.pre_relu ? relu4(d[2]) : d[2]) : zero;
+    };
+
+    f32x4 win[WIN][3], q[PF][S][3];
+    const int base0 = oy0 * S - p.pad_top;
+#pragma unroll
+    for (int k = 0; k < WIN - S; ++k) {
+        f32x4 d[3];
+        issue(base0 + k, d);
+        enter(base0 + k, d, win[S + k]);
+    }
+#pragma unroll
+    for (int j = 0; j < PF; ++j)
+#pragma unroll
+        for (int t = 0; t < S; ++t) issue(base0 + WIN - S + j * S + t, q[j][t]);
+    for (int r0 = 0; r0 < SROWS; r0 += PF) {
+#pragma unroll
+        for (int j = 0; j < PF; ++j) {
+            const int r = r0 + j;
+#pragma unroll
+            for (int k = 0; k < WIN - S; ++k) { win[k][0] = win[k + S][0]; win[k][1] = win[k + S][1]; win[k][2] = win[k + S][2]; }
+#pragma unroll
+            for (int t = 0; t < S; ++t) enter(base0 + r * S + WIN - S + t, q[j][t], win[WIN - S + t]);
+#pragma unroll
+            for (int t = 0; t < S; ++t) issue(base0 + (r + PF) * S + WIN - S + t, q[j][t]);   // past the strip: clamped re-read, unused
+            f32x4 acc = bv;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) acc += win[ky * R][kx] * wk[ky * 3 + kx];
+            if (p.post_relu) acc = relu4(acc);
+            *reinterpret_cast<f32x4*>(yout + (long long)(oy0 + r) * p.w_out * p.ldy) = acc;
+        }
     }
 }
 
@@ -258,15 +342,27 @@ __global__ __launch_bounds__(ATHREADS) void aspp_dw3_kernel(AsppArgs p) {
     const int b = blockIdx.y;
     const int hw = p.h * p.w_;
     const float* xin = p.x + (long long)b * hw * p.ldx;
-    for (int idx = tid; idx < hw * (ACB / 4); idx += ATHREADS) {
-        const int c4 = idx & 7, pix = idx >> 3;
-        const int ch = cb + c4 * 4;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (ch < p.c) {
-            v = *reinterpret_cast<const f32x4*>(xin + (long long)pix * p.ldx + ch);
-            if (p.pre_relu) v = relu4(v);
+    {   // stage the plane: 8 unconditional loads in flight per thread (clamped addresses), then the LDS stores --
+        // a load -> ReLU -> ds_write loop keeps ONE 16-byte load per thread in flight and leaves the CU idle on latency
+        constexpr int UN = 8;
+        const int total = hw * (ACB / 4);
+        const int sc4 = tid & 7;                               // ATHREADS % 8 == 0: the channel quad is fixed per thread
+        const bool ch_ok = cb + sc4 * 4 < p.c;
+        const float* src = xin + (ch_ok ? cb + sc4 * 4 : 0);
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        for (int base = tid; base < total; base += ATHREADS * UN) {
+            f32x4 v[UN];
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const int idx = min(base + u * ATHREADS, total - 1);
+                v[u] = *reinterpret_cast<const f32x4*>(src + (long long)(idx >> 3) * p.ldx);
+            }
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const int idx = base + u * ATHREADS;
+                if (idx < total) *reinterpret_cast<f32x4*>(plane + idx * 4) = ch_ok ? (p.pre_relu ? relu4(v[u]) : v[u]) : zero;
+            }
         }
-        *reinterpret_cast<f32x4*>(plane + idx * 4) = v;
     }
     __syncthreads();
     const int c4 = tid & 7, slot = tid >> 3;  // 64 pixel slots
@@ -337,9 +433,20 @@ __global__ __launch_bounds__(256) void dw_direct_kernel(DwArgs p) {
 template <int R, int S>
 void launch_stream(const DwArgs& p, hipStream_t s) {
     static const int srows_env = getenv("ASR_DW_SROWS") ? atoi(getenv("ASR_DW_SROWS")) : 0;
+    static const int pf_env = getenv("ASR_DW_PF") ? atoi(getenv("ASR_DW_PF")) : 0;
     const int tiles_x = (int)asr_cdiv(p.w_out, SCOLS), chunks = (int)asr_cdiv(p.c, 64);
     const int srows = srows_env ? srows_env : (p.h_out <= 32 ? 16 : 32);
     const dim3 grid(tiles_x * chunks, (unsigned)asr_cdiv(p.h_out, srows), p.batch);
+    // full strips (every layer of the net): the branch-free kernel; 4 rows in flight on the small OS16 maps (few waves
+    // per image), 1 on the large ones (measured).  ASR_DW_PF = 1 | 2 | 4 overrides, -1 = generic kernel.
+    const int pf = pf_env ? pf_env : (p.h_out <= 32 ? 4 : 1);
+    if (pf > 0 && p.h_out % srows == 0 && (srows == 16 || srows == 32)) {
+#define ASR_DW_FULL(SR_, PF_) hipLaunchKernelGGL((dw_stream_full_kernel<R, S, SR_, PF_>), grid, dim3(256), 0, s, p, tiles_x)
+        if (srows == 16) { if (pf == 1) ASR_DW_FULL(16, 1); else if (pf == 2) ASR_DW_FULL(16, 2); else ASR_DW_FULL(16, 4); }
+        else { if (pf == 1) ASR_DW_FULL(32, 1); else if (pf == 2) ASR_DW_FULL(32, 2); else ASR_DW_FULL(32, 4); }
+#undef ASR_DW_FULL
+        return;
+    }
     if (srows == 8) hipLaunchKernelGGL((dw_stream_kernel<R, S, 8>), grid, dim3(256), 0, s, p, tiles_x);
     else if (srows == 16) hipLaunchKernelGGL((dw_stream_kernel<R, S, 16>), grid, dim3(256), 0, s, p, tiles_x);
     else hipLaunchKernelGGL((dw_stream_kernel<R, S, 32>), grid, dim3(256), 0, s, p, tiles_x);
