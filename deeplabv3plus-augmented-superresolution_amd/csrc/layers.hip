@@ -48,6 +48,76 @@ __global__ __launch_bounds__(256) void conv3x3_direct_kernel(const float* __rest
     }
 }
 
+// ---- the stem: dense 3x3 on RGB, 32 output channels -------------------------------------------------------------
+// thread = (4 output channels, SP consecutive output pixels); the 8 lanes that share a pixel group each fetch 4 of a
+// pixel's 27 input values (instead of all 27: the texture-address path, 27 dword loads per 16 output bytes, bounded the
+// generic kernel at 1.0 TB/s) and hand them round with ds_bpermute; a weight quad read from LDS serves SP pixels.
+constexpr int SP = 4;
+
+__global__ __launch_bounds__(256) void conv3x3_stem_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                           const float* __restrict__ bias, float* __restrict__ y, int batch,
+                                                           int h_in, int w_in, int stride, int pad_top, int pad_left, int h_out,
+                                                           int w_out, int ldx, int ldy, int relu) {
+    constexpr int CIN = 3, COUT = 32, NE = 27;
+    __shared__ __attribute__((aligned(16))) float sw[NE * COUT];
+    for (int i = threadIdx.x; i < NE * COUT; i += 256) sw[i] = w[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int co4 = lane & 7;
+    const int groups_x = (w_out + SP - 1) / SP;
+    const long long total = (long long)batch * h_out * groups_x;          // pixel groups
+    const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + co4 * 4);
+    // every lane of a wave takes part in the exchanges: the loop bound is wave-uniform, late groups are masked
+    const long long waves_total = (total + 7) / 8;
+    for (long long wv = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); wv < waves_total; wv += (long long)gridDim.x * 4) {
+        const long long g = wv * 8 + (lane >> 3);
+        const bool g_ok = g < total;
+        const long long gc = g_ok ? g : total - 1;
+        const int gx = (int)(gc % groups_x);
+        long long t = gc / groups_x;
+        const int oy = (int)(t % h_out);
+        const long long b = t / h_out;
+        const float* xin = x + b * h_in * w_in * ldx;
+        // slot s of lane co4 holds input element e = s * 8 + co4 of each of the SP pixels (e = (ky * 3 + kx) * 3 + ci)
+        float val[SP][4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int e = s * 8 + co4;
+            const int tap = e / 3, ci = e - tap * 3, ky = tap / 3, kx = tap - ky * 3;
+            const int iy = oy * stride - pad_top + ky;
+#pragma unroll
+            for (int j = 0; j < SP; ++j) {
+                const int ox = gx * SP + j;
+                const int ix = ox * stride - pad_left + kx;
+                const bool in = e < NE && iy >= 0 && iy < h_in && ix >= 0 && ix < w_in;
+                const float v = xin[((long long)(in ? iy : 0) * w_in + (in ? ix : 0)) * ldx + (in ? ci : 0)];
+                val[j][s] = in ? v : 0.0f;
+            }
+        }
+        f32x4 acc[SP];
+#pragma unroll
+        for (int j = 0; j < SP; ++j) acc[j] = bv;
+        const int grp_base = lane & ~7;
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            const f32x4 wq = *reinterpret_cast<const f32x4*>(sw + e * COUT + co4 * 4);
+#pragma unroll
+            for (int j = 0; j < SP; ++j) acc[j] += __shfl(val[j][e >> 3], grp_base | (e & 7), 64) * wq;
+        }
+        if (g_ok) {
+#pragma unroll
+            for (int j = 0; j < SP; ++j) {
+                const int ox = gx * SP + j;
+                if (ox < w_out) {
+                    f32x4 a = acc[j];
+                    if (relu) { a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f); }
+                    *reinterpret_cast<f32x4*>(y + ((b * h_out + oy) * w_out + ox) * ldy + co4 * 4) = a;
+                }
+            }
+        }
+    }
+}
+
 // ---- global average pool: block = 64 channel-quads x 4 pixel groups ----------------------------
 __global__ __launch_bounds__(256) void gap_kernel(const float* __restrict__ x, float* __restrict__ y, int hw, int c, int ldx) {
     __shared__ f32x4 part[4][64];
@@ -117,6 +187,13 @@ extern "C" int asr_conv3x3_direct_f32(const float* x, const float* w, const floa
                     "asr_conv3x3_direct_f32: cout %% 4 == 0, ldy %% 4 == 0 and 9*cin*cout <= 12288 required (cin=%d cout=%d)", cin, cout);
     ASR_UNSUPPORTED((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(bias)) & 15,
                     "asr_conv3x3_direct_f32: y and bias must be 16-byte aligned");
+    if (cin == 3 && cout == 32) {
+        const long long waves = asr_cdiv((long long)batch * h_out * asr_cdiv(w_out, SP), 8);
+        hipLaunchKernelGGL(conv3x3_stem_kernel, dim3(cap_grid(waves * 64)), dim3(256), 0, asr_stream(stream), x, w, bias, y,
+                           batch, h_in, w_in, stride, pad_top, pad_left, h_out, w_out, ldx, ldy, relu);
+        ASR_LAUNCH_CHECK();
+        return ASR_OK;
+    }
     const long long total = (long long)batch * h_out * w_out * (cout >> 2);
     hipLaunchKernelGGL(conv3x3_direct_kernel, dim3(cap_grid(total)), dim3(256), sizeof(float) * 9 * cin * cout,
                        asr_stream(stream), x, w, bias, y, batch, h_in, w_in, cin, cout, stride, pad_top, pad_left, h_out,

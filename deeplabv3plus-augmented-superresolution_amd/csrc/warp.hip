@@ -40,11 +40,40 @@ __global__ __launch_bounds__(kThreads) void warp_affine_kernel(
 // ---- fused rotate -> translate from one shared source -----------------------------------
 // out[n,y,x,:] = bilinear_T( R_n ) where R_n(yr,xr,:) = bilinear_R(image) for in-bounds
 // integer (yr,xr) and 0 outside: exactly the two sequential resamplings of the reference.
+// All C channels of a tap travel together (one 12-byte load per tap for RGB instead of three 4-byte loads; the
+// coordinate arithmetic is shared): per channel the operations and their order are those of asr_tf_bilinear.
+template <int C>
+struct PixC {
+    float v[C];
+};
+typedef float asr_f3_a4 __attribute__((ext_vector_type(3), aligned(4)));   // an RGB pixel: 12 bytes, 4-byte aligned
+
+template <int C, class Read>
+__device__ __forceinline__ PixC<C> bilinear_c(Read rd, float ix, float iy) {
+    const float xf = floorf(ix), yf = floorf(iy);
+    const float xc = xf + 1.0f, yc = yf + 1.0f;
+    const int x0 = asr_coord_to_int(xf), y0 = asr_coord_to_int(yf);
+    const PixC<C> v00 = rd(y0, x0), v01 = rd(y0, x0 + 1);
+    const PixC<C> v10 = rd(y0 + 1, x0), v11 = rd(y0 + 1, x0 + 1);
+    const float wxl = xc - ix, wxh = ix - xf;
+    PixC<C> o;
+#pragma unroll
+    for (int ch = 0; ch < C; ++ch) {
+        const float vyf = wxl * v00.v[ch] + wxh * v01.v[ch];
+        const float vyc = wxl * v10.v[ch] + wxh * v11.v[ch];
+        o.v[ch] = (yc - iy) * vyf + (iy - yf) * vyc;
+    }
+    return o;
+}
+
 template <int C>
 __global__ __launch_bounds__(kThreads) void augment_copies_kernel(
     const float* __restrict__ image, float* __restrict__ copies,
     const float* __restrict__ rot_tf, const float* __restrict__ trans_tf, int n, int h, int w) {
     const int64_t total = (int64_t)n * h * w;
+    PixC<C> zero;
+#pragma unroll
+    for (int ch = 0; ch < C; ++ch) zero.v[ch] = 0.0f;
     for (int64_t p = (int64_t)blockIdx.x * kThreads + threadIdx.x; p < total;
          p += (int64_t)gridDim.x * kThreads) {
         const int x = (int)(p % w);
@@ -52,25 +81,38 @@ __global__ __launch_bounds__(kThreads) void augment_copies_kernel(
         const int b = (int)(p / ((int64_t)w * h));
         const AsrTf8 tr = asr_load_tf(rot_tf + (int64_t)b * 8);
         const AsrTf8 tt = asr_load_tf(trans_tf + (int64_t)b * 8);
-        float out[C];
         float ix, iy;
         const bool ok = asr_tf_map(tt, (float)x, (float)y, ix, iy);
+        auto rd_img = [&](int yy, int xx) -> PixC<C> {
+            const bool in = (yy >= 0 && yy < h && xx >= 0 && xx < w);
+            const float* q = image + ((int64_t)(in ? yy : 0) * w + (in ? xx : 0)) * C;   // clamped address
+            PixC<C> r;
+            if (C == 3) {
+                const asr_f3_a4 t = *reinterpret_cast<const asr_f3_a4*>(q);
+                r.v[0] = in ? t.x : 0.0f; r.v[1 % C] = in ? t.y : 0.0f; r.v[2 % C] = in ? t.z : 0.0f;
+            } else {
 #pragma unroll
-        for (int ch = 0; ch < C; ++ch) {
-            auto rd_img = [&](int yy, int xx) -> float {
-                return (yy >= 0 && yy < h && xx >= 0 && xx < w)
-                           ? image[((int64_t)yy * w + xx) * C + ch]
-                           : 0.0f;
-            };
-            auto rd_rot = [&](int yr, int xr) -> float {
-                if (!(yr >= 0 && yr < h && xr >= 0 && xr < w)) return 0.0f;
-                return asr_tf_sample(tr, rd_img, xr, yr);
-            };
-            out[ch] = ok ? asr_tf_bilinear(rd_rot, ix, iy) : 0.0f;
-        }
+                for (int ch = 0; ch < C; ++ch) {
+                    const float t = q[ch];
+                    r.v[ch] = in ? t : 0.0f;
+                }
+            }
+            return r;
+        };
+        auto rd_rot = [&](int yr, int xr) -> PixC<C> {       // branch-free: all 16 taps of a pixel can be in flight together
+            const bool inr = (yr >= 0 && yr < h && xr >= 0 && xr < w);
+            float rx, ry;
+            const bool okr = asr_tf_map(tr, (float)xr, (float)yr, rx, ry);
+            const PixC<C> v = bilinear_c<C>(rd_img, rx, ry);
+            PixC<C> r;
+#pragma unroll
+            for (int ch = 0; ch < C; ++ch) r.v[ch] = (inr && okr) ? v.v[ch] : 0.0f;
+            return r;
+        };
+        const PixC<C> out = ok ? bilinear_c<C>(rd_rot, ix, iy) : zero;
         float* o = copies + p * C;
 #pragma unroll
-        for (int ch = 0; ch < C; ++ch) o[ch] = out[ch];
+        for (int ch = 0; ch < C; ++ch) o[ch] = out.v[ch];
     }
 }
 
