@@ -307,7 +307,7 @@ __device__ long long g_phase_cycles[ASR_PHASE_BLOCKS * 8];
 #define PHASE_WAIT_LGKM()
 #endif
 
-template <int WM, int WN, int TM, int TN, bool DBUF, int MINW>
+template <int WM, int WN, int TM, int TN, bool DBUF, int MINW, bool CONV>
 __global__ __launch_bounds__(WM * WN * 64, MINW) void pw_gemm_f16x3_kernel(PwArgs p) {
     constexpr int NT = WM * WN * 64, BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int PA = BM * 4 / NT;                    // (row, 32-byte k-slot) items of the A tile per thread
@@ -332,18 +332,27 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void pw_gemm_f16x3_kernel(PwArg
     // A staging: thread owns k-slot (tid % 4) of rows (tid / 4) + i * (NT / 4)
     const int a_oct = tid & 3;
     const float* a_base[PA];
+    int a_oy[PA], a_ox[PA];                                     // CONV: top-left input pixel of the 3x3 window
 #pragma unroll
     for (int i = 0; i < PA; ++i) {
         const int row = (tid >> 2) + (NT / 4) * i;
         const long long m = (long long)tile_m * BM + row;
         a_base[i] = nullptr;
+        a_oy[i] = 0;
+        a_ox[i] = 0;
         if (m < p.M) {
             if (p.h_out > 0) {
                 const int ox = (int)(m % p.w_out);
                 const long long t = m / p.w_out;
                 const int oy = (int)(t % p.h_out);
                 const long long b = t / p.h_out;
-                a_base[i] = p.x + ((b * p.h_in + (long long)oy * p.stride) * p.w_in + (long long)ox * p.stride) * p.ldx;
+                if (CONV) {
+                    a_oy[i] = oy * p.stride - p.pad;
+                    a_ox[i] = ox * p.stride - p.pad;
+                    a_base[i] = p.x + b * (long long)p.h_in * p.w_in * p.ldx;
+                } else {
+                    a_base[i] = p.x + ((b * p.h_in + (long long)oy * p.stride) * p.w_in + (long long)ox * p.stride) * p.ldx;
+                }
             } else {
                 a_base[i] = p.x + m * p.ldx;
             }
@@ -357,10 +366,23 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void pw_gemm_f16x3_kernel(PwArg
 
     auto load_tile = [&](int kt) {
         const int k = kt * BK + a_oct * 8;
+        if (CONV) {                                            // implicit im2col: K-tile kt lies inside one tap (cin % 32 == 0)
+            const int tap = (kt * BK) / p.cin, coff = kt * BK - tap * p.cin + a_oct * 8;
+            const int dy = tap / 3, dx = tap - dy * 3;
 #pragma unroll
-        for (int i = 0; i < PA; ++i) {
-            ra[i][0] = (a_base[i] && k < p.K) ? *reinterpret_cast<const f32x4*>(a_base[i] + k) : zero4;
-            ra[i][1] = (a_base[i] && k + 4 < p.K) ? *reinterpret_cast<const f32x4*>(a_base[i] + k + 4) : zero4;
+            for (int i = 0; i < PA; ++i) {
+                const int iy = a_oy[i] + dy * p.dil, ix = a_ox[i] + dx * p.dil;
+                const bool in = a_base[i] && iy >= 0 && iy < p.h_in && ix >= 0 && ix < p.w_in;
+                const float* src = a_base[i] + ((long long)iy * p.w_in + ix) * p.ldx + coff;
+                ra[i][0] = in ? *reinterpret_cast<const f32x4*>(src) : zero4;
+                ra[i][1] = in ? *reinterpret_cast<const f32x4*>(src + 4) : zero4;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < PA; ++i) {
+                ra[i][0] = (a_base[i] && k < p.K) ? *reinterpret_cast<const f32x4*>(a_base[i] + k) : zero4;
+                ra[i][1] = (a_base[i] && k + 4 < p.K) ? *reinterpret_cast<const f32x4*>(a_base[i] + k + 4) : zero4;
+            }
         }
 #pragma unroll
         for (int i = 0; i < PB; ++i) {
@@ -647,6 +669,66 @@ extern "C" int asr_pwconv_pack_weights_f16x3(const float* w_kn, float* w_packed,
     return ASR_OK;
 }
 
+// Launch of the split-f16 kernels (shared by the pointwise and the 3x3 implicit-GEMM entry points).
+static int launch_f16x3(PwArgs a, int forced_shape, asr_stream_t stream) {
+    // Tile shape: 128x128 (4 waves of 64x64, one LDS stage, 3 workgroups per CU) everywhere.  Measured alternatives
+    // (ASR_F16X3_VARIANT, kept for experiments): 2 = 256x256, 8 waves of 64x128, two LDS stages, one workgroup per CU;
+    // 3 = 128x256, 4 waves of 64x128, two workgroups per CU.  Both stage fewer bytes per flop and came out within +-3 % of
+    // 128x128 (and 10-15 % behind it on the 728-channel middle flow): see DESIGN.md "GEMM phase profile".
+    static const int dbg = getenv("ASR_GEMM_DEBUG") ? atoi(getenv("ASR_GEMM_DEBUG")) : 0;
+    static const int variant = getenv("ASR_F16X3_VARIANT") ? atoi(getenv("ASR_F16X3_VARIANT")) : 0;
+    a.debug = dbg;
+    int shape = forced_shape ? forced_shape : (variant ? variant : 1);
+    if ((shape == 2 || shape == 3) && a.Npad % 256 != 0) shape = 1;
+    long long nwg = 0;
+#define ASR_F16X3_LAUNCH(WM_, WN_, TM_, TN_, DBUF_, MINW_, CONV_)                                                                    \
+    do {                                                                                                                 \
+        constexpr int bm = WM_ * TM_ * 32, bn = WN_ * TN_ * 32;                                                          \
+        constexpr size_t lds_stage = (size_t)(DBUF_ ? 2 : 1) * 2 * BK * (bm + bn) * sizeof(_Float16);                    \
+        constexpr size_t lds_epi = (size_t)WM_ * WN_ * 32 * TN_ * 32 * sizeof(float);                                    \
+        constexpr size_t lds = lds_stage > lds_epi ? lds_stage : lds_epi;                                                \
+        a.tiles_n = (int)asr_cdiv(a.N, bn);                                                                                \
+        nwg = asr_cdiv(a.M, bm) * a.tiles_n;                                                                               \
+        ASR_REQUIRE(nwg <= 0x7fffffffLL, "asr_pwconv_mfma_f16x3: grid too large");                                       \
+        auto kern = pw_gemm_f16x3_kernel<WM_, WN_, TM_, TN_, DBUF_, MINW_, CONV_>;                                              \
+        if (lds > 64 * 1024) {                                                                                           \
+            static bool attr_set = false;                                                                                \
+            if (!attr_set) {                                                                                             \
+                ASR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                   \
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                \
+                attr_set = true;                                                                                         \
+            }                                                                                                            \
+        }                                                                                                                \
+        hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(WM_ * WN_ * 64), lds, asr_stream(stream), a);                 \
+    } while (0)
+    switch (shape) {
+        case 2: ASR_F16X3_LAUNCH(4, 2, 2, 4, true, 2, false); break;
+        case 3: ASR_F16X3_LAUNCH(2, 2, 2, 4, false, 2, false); break;
+        case 8: ASR_F16X3_LAUNCH(2, 2, 2, 2, false, 1, true); break;      // 3x3 implicit GEMM, 128 x 128 tile
+        case 9: ASR_F16X3_LAUNCH(2, 2, 2, 1, false, 1, true); break;      // 3x3 implicit GEMM, 128 x 64 tile (cout <= 64)
+        default: ASR_F16X3_LAUNCH(2, 2, 2, 2, false, 1, false); break;
+    }
+#undef ASR_F16X3_LAUNCH
+    ASR_LAUNCH_CHECK();
+#ifdef ASR_GEMM_PHASE_PROFILE
+    {
+        static long long host[ASR_PHASE_BLOCKS * 8];
+        ASR_HIP_CHECK(hipDeviceSynchronize());
+        ASR_HIP_CHECK(hipMemcpyFromSymbol(host, HIP_SYMBOL(g_phase_cycles), sizeof(host)));
+        const long long nb = nwg < ASR_PHASE_BLOCKS ? nwg : ASR_PHASE_BLOCKS;
+        double mean[8] = {0};
+        for (long long b = 0; b < nb; ++b)
+            for (int i = 0; i < 8; ++i) mean[i] += (double)host[b * 8 + i] / (double)nb;
+        const int kt = (a.K + 31) / 32;
+        fprintf(stderr, "[phase] M=%lld K=%d N=%d blocks=%lld ksteps=%d | prologue %.0f | per k-step: issue %.0f  lds+mfma %.0f  vmwait %.0f  "
+                        "barrier1 %.0f  split+store %.0f  barrier2 %.0f | epilogue %.0f | block total %.0f cycles\n",
+                (long long)a.M, a.K, a.N, nwg, kt, mean[0], mean[1] / kt, mean[2] / kt, mean[3] / (kt - 1), mean[4] / (kt - 1), mean[5] / (kt - 1),
+                mean[6] / (kt - 1), mean[7], mean[0] + mean[1] + mean[2] + mean[3] + mean[4] + mean[5] + mean[6] + mean[7]);
+    }
+#endif
+    return ASR_OK;
+}
+
 extern "C" int asr_pwconv_mfma_f16x3(const float* x, const float* w_packed, const float* bias, const float* residual, float* y,
                                      int64_t m, int k, int n, int ldx, int ldy, int ldres, int relu, int sub_stride,
                                      int h_in, int w_in, asr_stream_t stream) {
@@ -667,58 +749,24 @@ extern "C" int asr_pwconv_mfma_f16x3(const float* x, const float* w_packed, cons
         ASR_REQUIRE(m % ((long long)a.h_out * a.w_out) == 0, "asr_pwconv_mfma_f16x3: m is not a whole number of %dx%d maps",
                     a.h_out, a.w_out);
     }
-    // Tile shape: 128x128 (4 waves of 64x64, one LDS stage, 3 workgroups per CU) everywhere.  Measured alternatives
-    // (ASR_F16X3_VARIANT, kept for experiments): 2 = 256x256, 8 waves of 64x128, two LDS stages, one workgroup per CU;
-    // 3 = 128x256, 4 waves of 64x128, two workgroups per CU.  Both stage fewer bytes per flop and came out within +-3 % of
-    // 128x128 (and 10-15 % behind it on the 728-channel middle flow): see DESIGN.md "GEMM phase profile".
-    static const int dbg = getenv("ASR_GEMM_DEBUG") ? atoi(getenv("ASR_GEMM_DEBUG")) : 0;
-    static const int variant = getenv("ASR_F16X3_VARIANT") ? atoi(getenv("ASR_F16X3_VARIANT")) : 0;
-    a.debug = dbg;
-    int shape = variant ? variant : 1;
-    if ((shape == 2 || shape == 3) && a.Npad % 256 != 0) shape = 1;
-    long long nwg = 0;
-#define ASR_F16X3_LAUNCH(WM_, WN_, TM_, TN_, DBUF_, MINW_)                                                                          \
-    do {                                                                                                                 \
-        constexpr int bm = WM_ * TM_ * 32, bn = WN_ * TN_ * 32;                                                          \
-        constexpr size_t lds_stage = (size_t)(DBUF_ ? 2 : 1) * 2 * BK * (bm + bn) * sizeof(_Float16);                    \
-        constexpr size_t lds_epi = (size_t)WM_ * WN_ * 32 * TN_ * 32 * sizeof(float);                                    \
-        constexpr size_t lds = lds_stage > lds_epi ? lds_stage : lds_epi;                                                \
-        a.tiles_n = (int)asr_cdiv(n, bn);                                                                                \
-        nwg = asr_cdiv(m, bm) * a.tiles_n;                                                                               \
-        ASR_REQUIRE(nwg <= 0x7fffffffLL, "asr_pwconv_mfma_f16x3: grid too large");                                       \
-        auto kern = pw_gemm_f16x3_kernel<WM_, WN_, TM_, TN_, DBUF_, MINW_>;                                                    \
-        if (lds > 64 * 1024) {                                                                                           \
-            static bool attr_set = false;                                                                                \
-            if (!attr_set) {                                                                                             \
-                ASR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                   \
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                \
-                attr_set = true;                                                                                         \
-            }                                                                                                            \
-        }                                                                                                                \
-        hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(WM_ * WN_ * 64), lds, asr_stream(stream), a);                 \
-    } while (0)
-    switch (shape) {
-        case 2: ASR_F16X3_LAUNCH(4, 2, 2, 4, true, 2); break;
-        case 3: ASR_F16X3_LAUNCH(2, 2, 2, 4, false, 2); break;
-        default: ASR_F16X3_LAUNCH(2, 2, 2, 2, false, 1); break;
-    }
-#undef ASR_F16X3_LAUNCH
-    ASR_LAUNCH_CHECK();
-#ifdef ASR_GEMM_PHASE_PROFILE
-    {
-        static long long host[ASR_PHASE_BLOCKS * 8];
-        ASR_HIP_CHECK(hipDeviceSynchronize());
-        ASR_HIP_CHECK(hipMemcpyFromSymbol(host, HIP_SYMBOL(g_phase_cycles), sizeof(host)));
-        const long long nb = nwg < ASR_PHASE_BLOCKS ? nwg : ASR_PHASE_BLOCKS;
-        double mean[8] = {0};
-        for (long long b = 0; b < nb; ++b)
-            for (int i = 0; i < 8; ++i) mean[i] += (double)host[b * 8 + i] / (double)nb;
-        const int kt = (k + 31) / 32;
-        fprintf(stderr, "[phase] M=%lld K=%d N=%d blocks=%lld ksteps=%d | prologue %.0f | per k-step: issue %.0f  lds+mfma %.0f  vmwait %.0f  "
-                        "barrier1 %.0f  split+store %.0f  barrier2 %.0f | epilogue %.0f | block total %.0f cycles\n",
-                (long long)m, k, n, nwg, kt, mean[0], mean[1] / kt, mean[2] / kt, mean[3] / (kt - 1), mean[4] / (kt - 1), mean[5] / (kt - 1),
-                mean[6] / (kt - 1), mean[7], mean[0] + mean[1] + mean[2] + mean[3] + mean[4] + mean[5] + mean[6] + mean[7]);
-    }
-#endif
-    return ASR_OK;
+    return launch_f16x3(a, 0, stream);
+}
+
+extern "C" int asr_conv3x3_mfma_f16x3(const float* x, const float* w_packed, const float* bias, float* y, int batch, int h_in,
+                                      int w_in, int cin, int cout, int stride, int pad, int dil, int h_out, int w_out, int ldx,
+                                      int ldy, int relu, asr_stream_t stream) {
+    const long long m = (long long)batch * h_out * w_out;
+    int rc = check_common("asr_conv3x3_mfma_f16x3", x, w_packed, y, m, 9 * cin, cout, ldx, ldy, nullptr, 0);
+    if (rc != ASR_OK) return rc;
+    ASR_REQUIRE(batch > 0 && h_in > 0 && w_in > 0 && h_out > 0 && w_out > 0 && stride > 0 && dil > 0 && pad >= 0,
+                "asr_conv3x3_mfma_f16x3: bad geometry");
+    ASR_UNSUPPORTED(cin % BK, "asr_conv3x3_mfma_f16x3: cin must be a multiple of %d (got %d)", BK, cin);
+    ASR_REQUIRE(ldx >= cin, "asr_conv3x3_mfma_f16x3: ldx < cin");
+    PwArgs a{};
+    a.x = x; a.wp = w_packed; a.bias = bias; a.res = nullptr; a.y = y;
+    a.M = m; a.K = 9 * cin; a.N = cout; a.Npad = round_up(cout, 128); a.Kpad = round_up(9 * cin, BK);
+    a.ldx = ldx; a.ldy = ldy; a.ldres = 0; a.relu = relu;
+    a.taps = 9; a.cin = cin; a.h_in = h_in; a.w_in = w_in; a.h_out = h_out; a.w_out = w_out;
+    a.stride = stride; a.pad = pad; a.dil = dil;
+    return launch_f16x3(a, cout <= 64 ? 9 : 8, stream);
 }

@@ -100,10 +100,12 @@ class DeeplabEngine:
                 (self._w[name + "/kernel"].reshape(-1, self._w[name + "/kernel"].shape[-1]).astype(np.float32),
                  self._w.get(name + "/bias")))
         kd = self._dev(k)
-        split = pack and self.precision == "f16x3" and k.shape[1] > 64 and name != "entry_flow_conv1_2"
+        conv = name == "entry_flow_conv1_2"                       # the one dense 3x3 on the matrix path (implicit GEMM)
+        split = pack and self.precision == "f16x3" and (k.shape[1] > 64 or conv)
         wdev = (ops.pack_pw_weights_f16x3(kd) if split else ops.pack_pw_weights(kd)) if pack else kd
-        self.p[name] = dict(w=wdev, b=self._dev(b) if b is not None else None, k=k.shape[0], n=k.shape[1],
-                            fn="asr_pwconv_mfma_f16x3" if split else "asr_pwconv_mfma_f32")
+        fn = ("asr_conv3x3_mfma_f16x3" if split else "asr_conv3x3_mfma_f32") if conv else \
+             ("asr_pwconv_mfma_f16x3" if split else "asr_pwconv_mfma_f32")
+        self.p[name] = dict(w=wdev, b=self._dev(b) if b is not None else None, k=k.shape[0], n=k.shape[1], fn=fn)
 
     def _put_dw(self, name, bn, eps):
         k, b = W.fold_dw_bn(self._w, name, bn, eps)
@@ -227,8 +229,8 @@ class DeeplabEngine:
             4.0 * (B * H * Wd * 3 + B * h1 * w1 * 32))
         a2 = new((B, h1, w1, 64))
         p = self.p["entry_flow_conv1_2"]
-        add("asr_conv3x3_mfma_f32", (a1.ptr, p["w"].data_ptr(), p["b"].data_ptr(), a2.ptr, B, h1, w1, 32, 64, 1, 1, 1, h1,
-                                     w1, 32, 64, 1), "conv", 2.0 * B * h1 * w1 * 288 * 64,
+        add(p["fn"], (a1.ptr, p["w"].data_ptr(), p["b"].data_ptr(), a2.ptr, B, h1, w1, 32, 64, 1, 1, 1, h1,
+                      w1, 32, 64, 1), "conv", 2.0 * B * h1 * w1 * 288 * 64,
             4.0 * (B * h1 * w1 * 96))
         release(a1)
         x = block(a2, "entry_flow_block1", "conv", 2, 1, False)

@@ -326,12 +326,14 @@ def pwconv(x, w_packed, bias, k, n, out=None, residual=None, relu=False, ldx=Non
     return out
 
 
-def conv3x3_mfma(x, w_packed, bias, cout, stride=1, pad=1, dil=1, relu=False):
+def conv3x3_mfma(x, w_packed, bias, cout, stride=1, pad=1, dil=1, relu=False, f16x3=False):
+    """Dense 3x3 as an implicit GEMM; w_packed from pack_pw_weights (f32 MFMA) or pack_pw_weights_f16x3 (f16x3=True)
+    on the [9 * cin, cout] matrix."""
     b, h, w, cin = x.shape
     ho = (h + 2 * pad - (2 * dil + 1)) // stride + 1
     wo = (w + 2 * pad - (2 * dil + 1)) // stride + 1
     y = torch.empty((b, ho, wo, cout), dtype=f32, device=x.device)
-    call("asr_conv3x3_mfma_f32", ptr(x), ptr(w_packed), ptr(bias, allow_none=True), ptr(y), b, h, w, cin, cout, stride,
+    call("asr_conv3x3_mfma_f16x3" if f16x3 else "asr_conv3x3_mfma_f32", ptr(x), ptr(w_packed), ptr(bias, allow_none=True), ptr(y), b, h, w, cin, cout, stride,
          pad, dil, ho, wo, cin, cout, int(relu), stream_ptr())
     return y
 

@@ -240,6 +240,12 @@ int asr_conv3x3_mfma_f32(const float* x, const float* w_packed, const float* bia
                          int w_in, int cin, int cout, int stride, int pad, int dil, int h_out, int w_out, int ldx,
                          int ldy, int relu, asr_stream_t stream);
 
+/* The same 3x3 implicit GEMM on the split-f16 matrix path (asr_pwconv_mfma_f16x3): w_packed from
+ * asr_pwconv_pack_weights_f16x3 on the [9 * cin, cout] matrix; cin % 32 == 0. */
+int asr_conv3x3_mfma_f16x3(const float* x, const float* w_packed, const float* bias, float* y, int batch, int h_in,
+                         int w_in, int cin, int cout, int stride, int pad, int dil, int h_out, int w_out, int ldx,
+                         int ldy, int relu, asr_stream_t stream);
+
 /* Conv2D 3x3 for tiny cin, weights HWIO [3,3,cin,cout]: entry_flow_conv1_1, model.py:150-153
  * ('same' with stride 2 on an even input pads bottom/right only: pad_top = pad_left = 0). */
 int asr_conv3x3_direct_f32(const float* x, const float* w, const float* bias, float* y, int batch, int h_in, int w_in,

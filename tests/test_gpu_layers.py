@@ -105,18 +105,25 @@ def test_pwconv_strided_rows_and_concat_output(dev):
     assert np.all(got[:, :16] == -7.0) and np.all(got[:, 16 + n:] == -7.0)
 
 
-def test_conv3x3_mfma_matches_conv2d(dev):
+@pytest.mark.parametrize("f16x3,cin,cout", [(False, 32, 64), (True, 32, 64), (True, 64, 160)])
+def test_conv3x3_mfma_matches_conv2d(dev, f16x3, cin, cout):
+    """entry_flow_conv1_2 as an implicit GEMM on the f32 and on the split-f16 matrix path (both f32-grade: the bound
+    is the summation-order noise of a 288- / 576-term f32 dot product)."""
     from asr_amd import ops
     rng = np.random.default_rng(12)
-    b, h, w_, cin, cout = 2, 20, 28, 32, 64
+    b, h, w_ = 2, 20, 28
     x = _rand(rng, b, h, w_, cin)
     k = _rand(rng, 3, 3, cin, cout, scale=0.08)
     bias = _rand(rng, cout)
     ref = F.conv2d(torch.from_numpy(x).permute(0, 3, 1, 2).double(), torch.from_numpy(k).permute(3, 2, 0, 1).double(),
                    torch.from_numpy(bias).double(), padding=1).relu().permute(0, 2, 3, 1).numpy()
-    wp = ops.pack_pw_weights(ops.to_device(k.reshape(9 * cin, cout)))
-    got = ops.conv3x3_mfma(ops.to_device(x), wp, ops.to_device(bias), cout, relu=True).cpu().numpy()
+    wk = ops.to_device(k.reshape(9 * cin, cout))
+    wp = ops.pack_pw_weights_f16x3(wk) if f16x3 else ops.pack_pw_weights(wk)
+    got = ops.conv3x3_mfma(ops.to_device(x), wp, ops.to_device(bias), cout, relu=True, f16x3=f16x3).cpu().numpy()
     np.testing.assert_allclose(got, ref, rtol=1e-4, atol=1e-4)
+    mag = F.conv2d(torch.from_numpy(np.abs(x)).permute(0, 3, 1, 2).double(), torch.from_numpy(np.abs(k)).permute(3, 2, 0, 1).double(),
+                   padding=1).permute(0, 2, 3, 1).numpy()
+    assert np.max(np.abs(got - ref) / (mag + 1e-30)) <= 4e-6
 
 
 def test_conv3x3_direct_same_padding_stride2(dev):
