@@ -62,6 +62,7 @@ SIGNATURES = {
     "asr_sr_solve_cfg_f32": (_i, [_vp] * 10 + [_i, _vp, _vp, _sz] + [_i] * 6 + [_fl] * 4 + [_cfg, _vp]),
     "asr_realign_max_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "asr_realign_mean_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "asr_realign_max_mean_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "asr_minmax_f32": (_i, [_vp, _vp, _i64, _i, _vp]),
     "asr_class_activation_f32": (_i, [_vp, _vp, _i64, _i, _i, _vp]),
     "asr_argmax_i32": (_i, [_vp, _vp, _i64, _i, _vp]),

@@ -420,8 +420,12 @@ __global__ __launch_bounds__(256) void sr_loss_prior_kernel(const float* __restr
 }
 
 // ---- realign: max / mean over copies of InvWarp(upsample(y_n)) (superresolution.py:139-161) --
-template <bool kMax>
-__global__ __launch_bounds__(256) void sr_realign_kernel(const float* __restrict__ y, float* __restrict__ out,
+// MODE 0: mean -> out_a; 1: max -> out_a; 2: both in one pass (max -> out_a, mean -> out_b): the reference calls
+// max_superresolution and mean_superresolution on the same copies (SR_single_class.py:103-110), and the per-copy value
+// is the expensive part.
+template <int MODE>
+__global__ __launch_bounds__(256) void sr_realign_kernel(const float* __restrict__ y, float* __restrict__ out_a,
+                                                         float* __restrict__ out_b,
                                                          const float* __restrict__ trans_tf /* translate(-s) */,
                                                          const float* __restrict__ rot_tf /* rotate(-theta) */,
                                                          SrDims d, float scale_y, float scale_x) {
@@ -430,7 +434,7 @@ __global__ __launch_bounds__(256) void sr_realign_kernel(const float* __restrict
     const int b = blockIdx.z;
     if (X >= d.W || Y >= d.H) return;
     const int H = d.H, W = d.W, lh = d.h, lw = d.w;
-    float acc = 0.0f;
+    float acc_sum = 0.0f, acc_max = 0.0f;
     for (int n = 0; n < d.n; ++n) {
         const int bn = b * d.n + n;
         const float* src = y + (int64_t)bn * lh * lw;
@@ -450,12 +454,55 @@ __global__ __launch_bounds__(256) void sr_realign_kernel(const float* __restrict
             if (!(yt >= 0 && yt < H && xt >= 0 && xt < W)) return 0.0f;
             return asr_tf_sample(tt, rd_up, xt, yt);
         };
-        const float val = asr_tf_sample(tr, rd_tr, X, Y);
-        if (kMax) acc = (n == 0) ? val : fmaxf(acc, val);
-        else acc += val;
+        float val;
+        // Pure translation (always, for tfa.image.translate): the 2 x 2 translate-stage pixels under the rotation sample
+        // read a 3 x 3 block of upsampled pixels (2 x 2 taps each, shifted by one); evaluate those 9 resize samples once
+        // instead of 16 times.  Same per-tap arithmetic as the generic path (bit-identical); the generic path stays for
+        // other transforms and for the float-rounding case where the two tap columns / rows do not abut.
+        float ix, iy;
+        const bool ok = asr_tf_map(tr, (float)X, (float)Y, ix, iy);
+        const float xf = floorf(ix), yf = floorf(iy);
+        const int x0 = asr_coord_to_int(xf), y0 = asr_coord_to_int(yf);
+        const bool pure_translation = (tt.a0 == 1.0f) & (tt.a1 == 0.0f) & (tt.b0 == 0.0f) & (tt.b1 == 1.0f) &
+                                      (tt.c0 == 0.0f) & (tt.c1 == 0.0f);
+        const float jx0 = (float)x0 + tt.a2, jx1 = (float)(x0 + 1) + tt.a2;
+        const float jy0 = (float)y0 + tt.b2, jy1 = (float)(y0 + 1) + tt.b2;
+        const float fx0 = floorf(jx0), fx1 = floorf(jx1), fy0 = floorf(jy0), fy1 = floorf(jy1);
+        const int cx0 = asr_coord_to_int(fx0), cx1 = asr_coord_to_int(fx1);
+        const int cy0 = asr_coord_to_int(fy0), cy1 = asr_coord_to_int(fy1);
+        if (ok && pure_translation && cx1 == cx0 + 1 && cy1 == cy0 + 1) {
+            float uv[3][3];
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) uv[a][c] = rd_up(cy0 + a, cx0 + c);
+            const float wxl0 = (fx0 + 1.0f) - jx0, wxh0 = jx0 - fx0, wxl1 = (fx1 + 1.0f) - jx1, wxh1 = jx1 - fx1;
+            const float wyl0 = (fy0 + 1.0f) - jy0, wyh0 = jy0 - fy0, wyl1 = (fy1 + 1.0f) - jy1, wyh1 = jy1 - fy1;
+            auto Tq = [&](int a, int c, float wxl, float wxh, float wyl, float wyh) -> float {
+                const float vyf = wxl * uv[a][c] + wxh * uv[a][c + 1];
+                const float vyc = wxl * uv[a + 1][c] + wxh * uv[a + 1][c + 1];
+                return wyl * vyf + wyh * vyc;
+            };
+            const bool vx0 = x0 >= 0 && x0 < W, vx1 = x0 + 1 >= 0 && x0 + 1 < W;
+            const bool vy0 = y0 >= 0 && y0 < H, vy1 = y0 + 1 >= 0 && y0 + 1 < H;
+            const float v00 = (vy0 && vx0) ? Tq(0, 0, wxl0, wxh0, wyl0, wyh0) : 0.0f;
+            const float v01 = (vy0 && vx1) ? Tq(0, 1, wxl1, wxh1, wyl0, wyh0) : 0.0f;
+            const float v10 = (vy1 && vx0) ? Tq(1, 0, wxl0, wxh0, wyl1, wyh1) : 0.0f;
+            const float v11 = (vy1 && vx1) ? Tq(1, 1, wxl1, wxh1, wyl1, wyh1) : 0.0f;
+            const float wxl = (xf + 1.0f) - ix, wxh = ix - xf;
+            const float vyf = wxl * v00 + wxh * v01;
+            const float vyc = wxl * v10 + wxh * v11;
+            val = ((yf + 1.0f) - iy) * vyf + (iy - yf) * vyc;
+        } else {
+            val = asr_tf_sample(tr, rd_tr, X, Y);
+        }
+        if (MODE != 0) acc_max = (n == 0) ? val : fmaxf(acc_max, val);
+        if (MODE != 1) acc_sum += val;
     }
-    if (!kMax) acc = acc / (float)d.n;
-    out[((int64_t)b * H + Y) * W + X] = acc;
+    const int64_t o = ((int64_t)b * H + Y) * W + X;
+    if (MODE == 0) out_a[o] = acc_sum / (float)d.n;
+    if (MODE == 1) out_a[o] = acc_max;
+    if (MODE == 2) { out_a[o] = acc_max; out_b[o] = acc_sum / (float)d.n; }
 }
 
 int check_dims(const char* fn, int batch, int n, int H, int W, int h, int w, SrDims* d) {
@@ -678,27 +725,33 @@ extern "C" int asr_sr_solve_f32(float* x, const float* y, const float* rot_tf, c
                                 lambda_l2, lambda_l1, &c, stream);
 }
 
-static int realign_common(bool is_max, const float* y, float* out, const float* trans_tf, const float* rot_tf,
+static int realign_common(int mode, const float* y, float* out_a, float* out_b, const float* trans_tf, const float* rot_tf,
                           int batch, int n, int H, int W, int h, int w, asr_stream_t stream) {
-    ASR_REQUIRE(y && out && trans_tf && rot_tf, "asr_realign: null pointer");
+    ASR_REQUIRE(y && out_a && trans_tf && rot_tf && (mode != 2 || out_b), "asr_realign: null pointer");
     ASR_REQUIRE(batch > 0 && batch <= 65535 && n > 0 && H > 0 && W > 0 && h > 0 && w > 0, "asr_realign: bad shape");
     SrDims d;
     d.batch = batch; d.n = n; d.H = H; d.W = W; d.h = h; d.w = w; d.f = 0;
     const float sy = (float)h / (float)H, sx = (float)w / (float)W;
-    if (is_max)
-        hipLaunchKernelGGL(sr_realign_kernel<true>, hr_grid(d), kBlock, 0, asr_stream(stream), y, out, trans_tf, rot_tf, d, sy, sx);
-    else
-        hipLaunchKernelGGL(sr_realign_kernel<false>, hr_grid(d), kBlock, 0, asr_stream(stream), y, out, trans_tf, rot_tf, d, sy, sx);
+    hipStream_t s = asr_stream(stream);
+    if (mode == 1) hipLaunchKernelGGL(sr_realign_kernel<1>, hr_grid(d), kBlock, 0, s, y, out_a, out_b, trans_tf, rot_tf, d, sy, sx);
+    else if (mode == 0) hipLaunchKernelGGL(sr_realign_kernel<0>, hr_grid(d), kBlock, 0, s, y, out_a, out_b, trans_tf, rot_tf, d, sy, sx);
+    else hipLaunchKernelGGL(sr_realign_kernel<2>, hr_grid(d), kBlock, 0, s, y, out_a, out_b, trans_tf, rot_tf, d, sy, sx);
     ASR_LAUNCH_CHECK();
     return ASR_OK;
 }
 
 extern "C" int asr_realign_max_f32(const float* y, float* out, const float* trans_tf, const float* rot_tf, int batch,
                                    int n, int H, int W, int h, int w, asr_stream_t stream) {
-    return realign_common(true, y, out, trans_tf, rot_tf, batch, n, H, W, h, w, stream);
+    return realign_common(1, y, out, nullptr, trans_tf, rot_tf, batch, n, H, W, h, w, stream);
 }
 
 extern "C" int asr_realign_mean_f32(const float* y, float* out, const float* trans_tf, const float* rot_tf, int batch,
                                     int n, int H, int W, int h, int w, asr_stream_t stream) {
-    return realign_common(false, y, out, trans_tf, rot_tf, batch, n, H, W, h, w, stream);
+    return realign_common(0, y, out, nullptr, trans_tf, rot_tf, batch, n, H, W, h, w, stream);
+}
+
+extern "C" int asr_realign_max_mean_f32(const float* y, float* out_max, float* out_mean, const float* trans_tf,
+                                        const float* rot_tf, int batch, int n, int H, int W, int h, int w,
+                                        asr_stream_t stream) {
+    return realign_common(2, y, out_max, out_mean, trans_tf, rot_tf, batch, n, H, W, h, w, stream);
 }

@@ -200,12 +200,18 @@ def sr_solve(x, y, rot_tf, trans_tf, inv_rot_tf, inv_trans_tf, alphas, lambdas, 
 
 
 def realign(y, trans_tf, rot_tf, out_hw, mode):
+    """mode "max" | "mean" -> [B,H,W]; "both" -> (max, mean) from one pass over the copies."""
     if y.dim() != 4:
         raise AsrError("realign: y must be [B,N,h,w]")
     b, n, h, w = y.shape
     _check_tf(trans_tf, b, n, "trans_tf")
     _check_tf(rot_tf, b, n, "rot_tf")
     out = torch.empty((b, out_hw[0], out_hw[1]), dtype=f32, device=y.device)
+    if mode == "both":
+        out_mean = torch.empty_like(out)
+        call("asr_realign_max_mean_f32", ptr(y), ptr(out), ptr(out_mean), ptr(trans_tf), ptr(rot_tf), b, n, out_hw[0],
+             out_hw[1], h, w, stream_ptr())
+        return out, out_mean
     fn = {"max": "asr_realign_max_f32", "mean": "asr_realign_mean_f32"}[mode]
     call(fn, ptr(y), ptr(out), ptr(trans_tf), ptr(rot_tf), b, n, out_hw[0], out_hw[1], h, w, stream_ptr())
     return out

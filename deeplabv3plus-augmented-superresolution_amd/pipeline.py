@@ -66,12 +66,18 @@ class HotPath:
     def _stage_sr(self, res, y, ymax, angles, shifts, gt_dev, adam_start, sr_types):
         sr = self.sr
         a, s = angles[None], shifts[None]
+        both = None
+        if "max" in sr_types and "mean" in sr_types:            # one pass over the copies serves both (bit-identical)
+            both = (sr.realign_batch(y, a, s, "both"), sr.realign_batch(ymax, a, s, "both") if ymax is not None else None)
         for t in sr_types:
             if t == "aug":
                 if adam_start is not None:
                     sr.optimizer.optimizer.iterations = adam_start
                 tgt, _ = sr.augmented_superresolution_batch(y, a, s)
                 tmax = sr.augmented_superresolution_batch(ymax, a, s)[0] if ymax is not None else None
+            elif both is not None:
+                k = 0 if t == "max" else 1
+                tgt, tmax = both[0][k], (both[1][k] if both[1] is not None else None)
             else:
                 tgt = sr.realign_batch(y, a, s, t)
                 tmax = sr.realign_batch(ymax, a, s, t) if ymax is not None else None

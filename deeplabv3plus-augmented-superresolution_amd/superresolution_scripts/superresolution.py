@@ -161,7 +161,8 @@ class Superresolution:
 
     # -- superresolution.py:139-161 ---------------------------------------------------------------------
     def realign_batch(self, copies, angles, shifts, mode):
-        """copies [B,N,h,w] device -> device [B,H,W]; translate(-shift) then rotate(-angle), max / mean."""
+        """copies [B,N,h,w] device -> device [B,H,W]; translate(-shift) then rotate(-angle), max / mean
+        (mode "both": the pair (max, mean) from one pass)."""
         rot, tr = self._transforms(angles, shifts, copies.device, negate=True)
         return ops.realign(copies, tr, rot, self.output_size, mode)
 

@@ -164,6 +164,11 @@ int asr_realign_max_f32(const float* y, float* out, const float* trans_tf, const
 int asr_realign_mean_f32(const float* y, float* out, const float* trans_tf, const float* rot_tf, int batch, int n,
                          int H, int W, int h, int w, asr_stream_t stream);
 
+/* Both of the above in one pass over the copies (the reference computes max- and mean-SR of the same
+ * copies, SR_single_class.py:103-110): out_max / out_mean [batch,H,W], bit-identical to the two calls. */
+int asr_realign_max_mean_f32(const float* y, float* out_max, float* out_mean, const float* trans_tf,
+                             const float* rot_tf, int batch, int n, int H, int W, int h, int w, asr_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Output processing, thresholding, IoU
  * ------------------------------------------------------------------------------------------ */

@@ -180,6 +180,9 @@ def test_realign_matches_oracle(dev, mode):
         fn = sr.max_superresolution if mode == "max" else sr.mean_superresolution
         ref, _ = fn(y[i][..., None], angs[i], shs[i])
         np.testing.assert_allclose(got[i], ref[:, :, 0], rtol=0, atol=2e-6)
+    # the fused pass returns exactly what the two separate calls return
+    mx, mn = ops.realign(ops.to_device(y), ops.to_device(tr_neg), ops.to_device(rot_neg), (H, H), "both")
+    assert np.array_equal((mx if mode == "max" else mn).cpu().numpy(), got)
 
 
 def test_threshold_and_iou_bit_exact(dev):
