@@ -219,19 +219,29 @@ __global__ __launch_bounds__(256) void sr_backward_adam_kernel(
                 const int xa = (cxa == big) ? 0 : cxa, xb = max(cxb, 0), ya = (cya == big) ? 0 : cya, yb = max(cyb, 0);
                 const float saa = (two_lambda_df * r[ya * lw + xa]) * 0.25f, sab = (two_lambda_df * r[ya * lw + xb]) * 0.25f;
                 const float sba = (two_lambda_df * r[yb * lw + xa]) * 0.25f, sbb = (two_lambda_df * r[yb * lw + xb]) * 0.25f;
-                auto gt_sel = [&](int ly, int lx) -> float {
-                    const float row_a = (lx == cxa) ? saa : sab, row_b = (lx == cxa) ? sba : sbb;
-                    const float v = (ly == cya) ? row_a : row_b;
-                    return ((ly >= 0) & (lx >= 0)) ? v : 0.0f;
+                // The 16 taps select among the four cell values; selection and the x blend commute with the row choice,
+                // so the x blend is done ONCE per (tap column pair, cell row) and the taps only pick a row afterwards --
+                // the same products and sums on the same operands as tap-by-tap selection (an invalid tap contributes
+                // w * 0 = +0 either way), a third of the v_cndmask / compare instructions this VALU-bound loop spent.
+                auto cell = [&](int lx, float va, float vb) -> float {           // value of column lx in one cell row
+                    const float v = (lx == cxa) ? va : vb;
+                    return (lx >= 0) ? v : 0.0f;
                 };
-                auto gr = [&](const SrAxisTap& ay, const SrAxisTap& ax) -> float {   // G_R at one integer position
-                    const float vyf = ax.wl * gt_sel(ay.l0, ax.l0) + ax.wh * gt_sel(ay.l0, ax.l1);
-                    const float vyc = ax.wl * gt_sel(ay.l1, ax.l0) + ax.wh * gt_sel(ay.l1, ax.l1);
-                    const float v = ay.wl * vyf + ay.wh * vyc;
+                auto hx = [&](const SrAxisTap& ax, float va, float vb) -> float {   // x blend of a tap column pair in one cell row
+                    return ax.wl * cell(ax.l0, va, vb) + ax.wh * cell(ax.l1, va, vb);
+                };
+                const float h0a = hx(ax0, saa, sab), h0b = hx(ax0, sba, sbb);
+                const float h1a = hx(ax1, saa, sab), h1b = hx(ax1, sba, sbb);
+                auto row = [&](int ly, float ha, float hb) -> float {              // the x-blended value of tap row ly
+                    const float v = (ly == cya) ? ha : hb;
+                    return (ly >= 0) ? v : 0.0f;
+                };
+                auto gr = [&](const SrAxisTap& ay, const SrAxisTap& ax, float ha, float hb) -> float {   // G_R at one integer position
+                    const float v = ay.wl * row(ay.l0, ha, hb) + ay.wh * row(ay.l1, ha, hb);
                     return (ay.inb & ax.inb) ? v : 0.0f;
                 };
-                const float vyf = wxl * gr(ay0, ax0) + wxh * gr(ay0, ax1);
-                const float vyc = wxl * gr(ay1, ax0) + wxh * gr(ay1, ax1);
+                const float vyf = wxl * gr(ay0, ax0, h0a, h0b) + wxh * gr(ay0, ax1, h1a, h1b);
+                const float vyc = wxl * gr(ay1, ax0, h0a, h0b) + wxh * gr(ay1, ax1, h1a, h1b);
                 g_df += ((yf + 1.0f) - iy) * vyf + (iy - yf) * vyc;
             } else {   // > 2 distinct cells on an axis: only through float rounding at a binade edge; 16 direct gathers
                 auto gr = [&](const SrAxisTap& ay, const SrAxisTap& ax) -> float {
