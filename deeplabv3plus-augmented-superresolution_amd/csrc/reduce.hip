@@ -64,14 +64,53 @@ __device__ __forceinline__ int argmax_row(const float* __restrict__ row, int cla
     return arg;
 }
 
+// The class rows are 4 * classes bytes apart (84 for 21 classes): a thread walking its own row makes every wave-load a
+// 64-way strided gather that pulls whole cache lines for 4 bytes each (PMC: 7.3x the logits' bytes fetched).  A
+// workgroup therefore copies its 256 consecutive rows into LDS with coalesced loads and the threads walk the LDS rows
+// (stride of `classes` words: conflict-free for odd class counts such as 21).  kMaxStageClasses bounds the LDS tile.
+constexpr int kMaxStageClasses = 32;
+
+__device__ __forceinline__ const float* stage_rows(const float* __restrict__ logits, int64_t first, int64_t pixels, int classes,
+                                                   float* __restrict__ tile) {
+    const int64_t rows = min((int64_t)256, pixels - first);
+    const int64_t n = rows * classes;
+    const float* src = logits + first * classes;
+    for (int64_t i = threadIdx.x; i < n; i += 256) tile[i] = src[i];
+    __syncthreads();
+    return tile + (int64_t)threadIdx.x * classes;
+}
+
 __global__ __launch_bounds__(256) void argmax_kernel(const float* __restrict__ logits, int32_t* __restrict__ out,
                                                      int64_t pixels, int classes) {
-    for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < pixels; p += (int64_t)gridDim.x * 256)
-        out[p] = argmax_row(logits + p * classes, classes);
+    __shared__ float tile[256 * kMaxStageClasses];
+    for (int64_t first = (int64_t)blockIdx.x * 256; first < pixels; first += (int64_t)gridDim.x * 256) {
+        const float* row = stage_rows(logits, first, pixels, classes, tile);
+        const int64_t p = first + threadIdx.x;
+        if (p < pixels) out[p] = argmax_row(row, classes);
+        __syncthreads();
+    }
 }
 
 __global__ __launch_bounds__(256) void opm_argmax_kernel(const float* __restrict__ logits, float* __restrict__ out,
                                                          int64_t pixels, int classes, int class_id) {
+    __shared__ float tile[256 * kMaxStageClasses];
+    for (int64_t first = (int64_t)blockIdx.x * 256; first < pixels; first += (int64_t)gridDim.x * 256) {
+        const float* row = stage_rows(logits, first, pixels, classes, tile);
+        const int64_t p = first + threadIdx.x;
+        if (p < pixels) out[p] = (argmax_row(row, classes) == class_id) ? (float)class_id : 0.0f;
+        __syncthreads();
+    }
+}
+
+// same walks straight from global memory, for class counts beyond the LDS tile
+__global__ __launch_bounds__(256) void argmax_direct_kernel(const float* __restrict__ logits, int32_t* __restrict__ out,
+                                                            int64_t pixels, int classes) {
+    for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < pixels; p += (int64_t)gridDim.x * 256)
+        out[p] = argmax_row(logits + p * classes, classes);
+}
+
+__global__ __launch_bounds__(256) void opm_argmax_direct_kernel(const float* __restrict__ logits, float* __restrict__ out,
+                                                                int64_t pixels, int classes, int class_id) {
     for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < pixels; p += (int64_t)gridDim.x * 256)
         out[p] = (argmax_row(logits + p * classes, classes) == class_id) ? (float)class_id : 0.0f;
 }
@@ -203,7 +242,10 @@ extern "C" int asr_minmax_f32(const float* x, float* out_minmax, int64_t per_seg
 extern "C" int asr_argmax_i32(const float* logits, int32_t* out, int64_t pixels, int classes, asr_stream_t stream) {
     ASR_REQUIRE(logits && out, "asr_argmax_i32: null pointer");
     ASR_REQUIRE(pixels > 0 && classes > 0, "asr_argmax_i32: bad shape");
-    hipLaunchKernelGGL(argmax_kernel, dim3(stream_grid(pixels)), dim3(256), 0, asr_stream(stream), logits, out, pixels, classes);
+    if (classes <= kMaxStageClasses)
+        hipLaunchKernelGGL(argmax_kernel, dim3(stream_grid(pixels)), dim3(256), 0, asr_stream(stream), logits, out, pixels, classes);
+    else
+        hipLaunchKernelGGL(argmax_direct_kernel, dim3(stream_grid(pixels)), dim3(256), 0, asr_stream(stream), logits, out, pixels, classes);
     ASR_LAUNCH_CHECK();
     return ASR_OK;
 }
@@ -212,8 +254,12 @@ extern "C" int asr_opm_argmax_f32(const float* logits, float* class_mask, int64_
                                   asr_stream_t stream) {
     ASR_REQUIRE(logits && class_mask, "asr_opm_argmax_f32: null pointer");
     ASR_REQUIRE(pixels > 0 && classes > 0 && class_id >= 0 && class_id < classes, "asr_opm_argmax_f32: bad shape/class");
-    hipLaunchKernelGGL(opm_argmax_kernel, dim3(stream_grid(pixels)), dim3(256), 0, asr_stream(stream), logits, class_mask,
-                       pixels, classes, class_id);
+    if (classes <= kMaxStageClasses)
+        hipLaunchKernelGGL(opm_argmax_kernel, dim3(stream_grid(pixels)), dim3(256), 0, asr_stream(stream), logits, class_mask,
+                           pixels, classes, class_id);
+    else
+        hipLaunchKernelGGL(opm_argmax_direct_kernel, dim3(stream_grid(pixels)), dim3(256), 0, asr_stream(stream), logits,
+                           class_mask, pixels, classes, class_id);
     ASR_LAUNCH_CHECK();
     return ASR_OK;
 }

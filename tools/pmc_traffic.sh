@@ -6,6 +6,7 @@ set -e
 out=${1:-$GRAFT_REPO_ROOT/gpurun_out/pmc_traffic}
 repo=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 mkdir -p "$out"
+out=$(cd "$out" && pwd)                     # absolute: the passes run from /tmp
 cd /tmp && export TMPDIR=/tmp
 for ctr in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d "$out/$ctr" -- python3 "$repo/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > "$out/$ctr.log" 2>&1
