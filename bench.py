@@ -289,9 +289,11 @@ def main():
             dms, _dfl, dby, dl = prof["dw"]
             gbs = dby / (dms * 1e-3) / 1e9
             out["roofline_depthwise"] = {
-                "kernel": "dw_stream_kernel / aspp_dw3_kernel (asr_dwconv3x3_nhwc_f32, asr_aspp_dwconv3_nhwc_f32)", "bound": "hbm",
+                "kernel": "dw_stream_full_kernel / aspp_dw3_kernel (asr_dwconv3x3_nhwc_f32, asr_aspp_dwconv3_nhwc_f32)", "bound": "hbm",
                 "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
-                "traffic": None, "launches": dl, "avg_launch_ms": round(dms / dl, 4),
+                "traffic": pmc_lookup("dw_stream_full_kernel<"), "algorithmic_bytes_per_launch": round(dby / dl),
+                "traffic_note": "launch-weighted mean HBM bytes of the dw_stream_full_kernel launches (PMC, as above)",
+                "launches": dl, "avg_launch_ms": round(dms / dl, 4),
             }
         out["kernel_time_ms_per_step"] = {k: round(v[0], 3) for k, v in prof.items() if not k.startswith("_")}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
