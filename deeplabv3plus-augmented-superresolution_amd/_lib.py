@@ -50,6 +50,7 @@ SIGNATURES = {
     "asr_abi_version": (_i, []),
     "asr_target_arch": (C.c_char_p, []),
     "asr_warp_affine_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "asr_warp_affine_nearest_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "asr_augment_copies_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "asr_sr_init_target_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "asr_sr_forward_residual_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
@@ -71,6 +72,7 @@ SIGNATURES = {
     "asr_opm_slice_f32": (_i, [_vp, _vp, _vp, _i, _i64, _i, _i, _fl, _fl, _vp]),
     "asr_threshold_f32": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _fl, _i, _vp]),
     "asr_iou_counts_i32": (_i, [_vp, _vp, _vp, _i64, _i, _i, _i, _vp]),
+    "asr_class_counts_i32": (_i, [_vp, _vp, _vp, _i64, _i, _vp]),
     "asr_pwconv_packed_floats": (_sz, [_i, _i]),
     "asr_pwconv_pack_weights_f32": (_i, [_vp, _vp, _i, _i, _vp]),
     "asr_pwconv_mfma_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),

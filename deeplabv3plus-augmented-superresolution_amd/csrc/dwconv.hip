@@ -40,6 +40,12 @@ __device__ __forceinline__ f32x4 relu4(f32x4 v) {
     v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
     return v;
 }
+// post-activation selector of the C ABI: 0 none, 1 ReLU, 2 ReLU6 (MobileNetV2)
+__device__ __forceinline__ f32x4 post_act4(f32x4 v, int mode) {
+    if (mode) v = relu4(v);
+    if (mode == 2) { v.x = fminf(v.x, 6.f); v.y = fminf(v.y, 6.f); v.z = fminf(v.z, 6.f); v.w = fminf(v.w, 6.f); }
+    return v;
+}
 
 // ---------------------------------------------------------------------------------------------
 // LDS-tiled, stride 1
@@ -93,7 +99,7 @@ __global__ __launch_bounds__(256) void dw_tiled_kernel(DwArgs p, int tiles_x) {
                 const f32x4 v = *reinterpret_cast<const f32x4*>(tile + (((r + ky * R) * COLS + col + kx * R) * (CB / 4) + c4) * 4);
                 acc += v * wk[ky * 3 + kx];
             }
-        if (p.post_relu) acc = relu4(acc);
+        acc = post_act4(acc, p.post_relu);
         *reinterpret_cast<f32x4*>(yout + ((long long)oy * p.w_out + ox) * p.ldy + ch) = acc;
     }
 }
@@ -163,7 +169,7 @@ __global__ __launch_bounds__(256) void dw_stream_kernel(DwArgs p, int tiles_x) {
         for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) acc += win[ky * R][kx] * wk[ky * 3 + kx];
-        if (p.post_relu) acc = relu4(acc);
+        acc = post_act4(acc, p.post_relu);
         *reinterpret_cast<f32x4*>(yout + ((long long)(oy0 + r) * p.w_out + ox) * p.ldy) = acc;
     }
 }
@@ -240,7 +246,7 @@ __global__ __launch_bounds__(256) void dw_stream_full_kernel(DwArgs p, int tiles
             for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx) acc += win[ky * R][kx] * wk[ky * 3 + kx];
-            if (p.post_relu) acc = relu4(acc);
+            acc = post_act4(acc, p.post_relu);
             *reinterpret_cast<f32x4*>(yout + (long long)(oy0 + r) * p.w_out * p.ldy) = acc;
         }
     }
@@ -302,7 +308,7 @@ __global__ __launch_bounds__(256) void dw_flat_kernel(DwArgs p, int pieces_per_r
         for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) acc += win[ky * R][kx] * wk[ky * 3 + kx];
-        if (p.post_relu) acc = relu4(acc);
+        acc = post_act4(acc, p.post_relu);
         *reinterpret_cast<f32x4*>(yout + (oy0 + r) * out_stride) = acc;
     }
 }
@@ -391,7 +397,7 @@ __global__ __launch_bounds__(ATHREADS) void aspp_dw3_kernel(AsppArgs p) {
                     acc += *reinterpret_cast<const f32x4*>(plane + ((iy * p.w_ + ix) * (ACB / 4) + c4) * 4) * wk[ky * 3 + kx];
                 }
             }
-            if (p.post_relu) acc = relu4(acc);
+            acc = post_act4(acc, p.post_relu);
             *reinterpret_cast<f32x4*>(yout + (long long)pix * p.ldy) = acc;
         }
     }
@@ -425,7 +431,7 @@ __global__ __launch_bounds__(256) void dw_direct_kernel(DwArgs p) {
                 acc += v * *reinterpret_cast<const f32x4*>(p.w + (long long)(ky * 3 + kx) * p.c + ch);
             }
         }
-        if (p.post_relu) acc = relu4(acc);
+        acc = post_act4(acc, p.post_relu);
         *reinterpret_cast<f32x4*>(p.y + ((b * p.h_out + oy) * p.w_out + ox) * p.ldy + ch) = acc;
     }
 }

@@ -77,6 +77,7 @@ __device__ __forceinline__ void pw_epilogue(const PwArgs& p, f32x16 (&acc)[TM][T
             for (int e = 0; e < 16; ++e) {
                 float v = acc[i][j][e] + bv;
                 if (p.relu) v = fmaxf(v, 0.f);
+                if (p.relu == 2) v = fminf(v, 6.f);          // ReLU6 (MobileNetV2 blocks)
                 stage[((e & 3) + 8 * (e >> 2) + 4 * hh) * WCOLS + j * 32 + l32] = v;
             }
         }

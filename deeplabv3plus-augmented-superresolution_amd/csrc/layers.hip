@@ -44,6 +44,7 @@ __global__ __launch_bounds__(256) void conv3x3_direct_kernel(const float* __rest
             }
         }
         if (relu) { acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f); }
+        if (relu == 2) { acc.x = fminf(acc.x, 6.f); acc.y = fminf(acc.y, 6.f); acc.z = fminf(acc.z, 6.f); acc.w = fminf(acc.w, 6.f); }
         *reinterpret_cast<f32x4*>(y + ((b * h_out + oy) * w_out + ox) * ldy + co4 * 4) = acc;
     }
 }
@@ -58,7 +59,7 @@ __global__ __launch_bounds__(256) void conv3x3_stem_kernel(const float* __restri
                                                            const float* __restrict__ bias, float* __restrict__ y, int batch,
                                                            int h_in, int w_in, int stride, int pad_top, int pad_left, int h_out,
                                                            int w_out, int ldx, int ldy, int relu) {
-    constexpr int CIN = 3, COUT = 32, NE = 27;
+    constexpr int COUT = 32, NE = 27;                        // 3 input channels x 9 taps
     __shared__ __attribute__((aligned(16))) float sw[NE * COUT];
     for (int i = threadIdx.x; i < NE * COUT; i += 256) sw[i] = w[i];
     __syncthreads();
@@ -111,6 +112,7 @@ __global__ __launch_bounds__(256) void conv3x3_stem_kernel(const float* __restri
                 if (ox < w_out) {
                     f32x4 a = acc[j];
                     if (relu) { a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f); }
+                    if (relu == 2) { a.x = fminf(a.x, 6.f); a.y = fminf(a.y, 6.f); a.z = fminf(a.z, 6.f); a.w = fminf(a.w, 6.f); }
                     *reinterpret_cast<f32x4*>(y + ((b * h_out + oy) * w_out + ox) * ldy + co4 * 4) = a;
                 }
             }

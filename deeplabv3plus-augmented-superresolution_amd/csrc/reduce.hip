@@ -197,6 +197,28 @@ __global__ __launch_bounds__(256) void iou_counts_kernel(const int32_t* __restri
     }
 }
 
+// ---- per-label counts for Mean_IOU (utils.py:151-177) -----------------------------------------------------------
+// counts[seg][0][l] = |truth == l|, [1][l] = |pred == l|, [2][l] = |truth == l & pred == l| for labels 0..255
+// (union = [0] + [1] - [2]); labels outside 0..255 are not counted.
+__global__ __launch_bounds__(256) void class_counts_kernel(const int32_t* __restrict__ truth, const int32_t* __restrict__ pred,
+                                                           unsigned long long* __restrict__ counts, int64_t per_seg) {
+    __shared__ unsigned int hist[3 * 256];
+    const int seg = blockIdx.y;
+    for (int i = threadIdx.x; i < 3 * 256; i += 256) hist[i] = 0;
+    __syncthreads();
+    const int32_t* t = truth + (int64_t)seg * per_seg;
+    const int32_t* q = pred + (int64_t)seg * per_seg;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < per_seg; i += (int64_t)gridDim.x * 256) {
+        const int tv = t[i], pv = q[i];
+        if (tv >= 0 && tv < 256) atomicAdd(hist + tv, 1u);
+        if (pv >= 0 && pv < 256) atomicAdd(hist + 256 + pv, 1u);
+        if (tv == pv && tv >= 0 && tv < 256) atomicAdd(hist + 512 + tv, 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 3 * 256; i += 256)
+        if (hist[i]) atomicAdd(counts + (int64_t)seg * 768 + i, (unsigned long long)hist[i]);
+}
+
 // ---- last_activation: softmax / sigmoid over the class axis (model.py:124-125) ----------------------
 __global__ __launch_bounds__(256) void class_activation_kernel(const float* __restrict__ logits, float* __restrict__ out,
                                                               int64_t pixels, int classes, int kind) {
@@ -313,6 +335,19 @@ extern "C" int asr_iou_counts_i32(const int32_t* truth, const int32_t* pred, int
     hipLaunchKernelGGL(iou_counts_kernel, dim3(stream_grid(per_segment) > 64 ? 64 : stream_grid(per_segment), segments),
                        dim3(256), 0, s, truth, pred, reinterpret_cast<unsigned long long*>(counts), per_segment, class_id,
                        include_bg);
+    ASR_LAUNCH_CHECK();
+    return ASR_OK;
+}
+
+extern "C" int asr_class_counts_i32(const int32_t* truth, const int32_t* pred, int64_t* counts, int64_t per_segment,
+                                    int segments, asr_stream_t stream) {
+    ASR_REQUIRE(truth && pred && counts, "asr_class_counts_i32: null pointer");
+    ASR_REQUIRE(per_segment > 0 && segments > 0 && segments <= 65535, "asr_class_counts_i32: bad shape");
+    hipStream_t s = asr_stream(stream);
+    ASR_HIP_CHECK(hipMemsetAsync(counts, 0, sizeof(int64_t) * 768 * (size_t)segments, s));
+    const int grid = stream_grid(per_segment) > 64 ? 64 : stream_grid(per_segment);
+    hipLaunchKernelGGL(class_counts_kernel, dim3(grid, segments), dim3(256), 0, s, truth, pred,
+                       reinterpret_cast<unsigned long long*>(counts), per_segment);
     ASR_LAUNCH_CHECK();
     return ASR_OK;
 }

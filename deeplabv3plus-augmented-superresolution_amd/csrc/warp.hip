@@ -11,7 +11,9 @@ namespace {
 constexpr int kThreads = 256;
 
 // ---- generic single-stage warp ----------------------------------------------------------
-// One thread per output pixel, all C channels (runtime C).
+// One thread per output pixel, all C channels (runtime C).  NEAREST: ImageProjectiveTransformV3 with interpolation
+// "NEAREST" (the label maps of check_robustness.py:45-50): I(round(in_y), round(in_x)), std::round, 0 outside.
+template <bool NEAREST>
 __global__ __launch_bounds__(kThreads) void warp_affine_kernel(
     const float* __restrict__ src, float* __restrict__ dst, const float* __restrict__ tfs,
     int n, int src_batched, int tf_batched, int h_in, int w_in, int h_out, int w_out, int c) {
@@ -26,6 +28,13 @@ __global__ __launch_bounds__(kThreads) void warp_affine_kernel(
         float ix, iy;
         const bool ok = asr_tf_map(t, (float)x, (float)y, ix, iy);
         float* o = dst + p * c;
+        if (NEAREST) {
+            const float ry = roundf(iy), rx = roundf(ix);
+            const bool in = ok && ry >= 0.0f && ry < (float)h_in && rx >= 0.0f && rx < (float)w_in;
+            const float* q = img + ((int64_t)(in ? (int)ry : 0) * w_in + (in ? (int)rx : 0)) * c;
+            for (int ch = 0; ch < c; ++ch) o[ch] = in ? q[ch] : 0.0f;
+            continue;
+        }
         for (int ch = 0; ch < c; ++ch) {
             auto rd = [&](int yy, int xx) -> float {
                 return (yy >= 0 && yy < h_in && xx >= 0 && xx < w_in)
@@ -132,7 +141,21 @@ extern "C" int asr_warp_affine_f32(const float* src, float* dst, const float* tr
                 "asr_warp_affine_f32: bad shape n=%d in=%dx%d out=%dx%d c=%d", n, h_in, w_in, h_out,
                 w_out, c);
     const int64_t total = (int64_t)n * h_out * w_out;
-    hipLaunchKernelGGL(warp_affine_kernel, dim3(grid_for(total)), dim3(kThreads), 0, asr_stream(stream),
+    hipLaunchKernelGGL(warp_affine_kernel<false>, dim3(grid_for(total)), dim3(kThreads), 0, asr_stream(stream),
+                       src, dst, transforms, n, src_batched, tf_batched, h_in, w_in, h_out, w_out, c);
+    ASR_LAUNCH_CHECK();
+    return ASR_OK;
+}
+
+extern "C" int asr_warp_affine_nearest_f32(const float* src, float* dst, const float* transforms, int n,
+                                           int src_batched, int tf_batched, int h_in, int w_in, int h_out,
+                                           int w_out, int c, asr_stream_t stream) {
+    ASR_REQUIRE(src && dst && transforms, "asr_warp_affine_nearest_f32: null pointer");
+    ASR_REQUIRE(n > 0 && h_in > 0 && w_in > 0 && h_out > 0 && w_out > 0 && c > 0,
+                "asr_warp_affine_nearest_f32: bad shape n=%d in=%dx%d out=%dx%d c=%d", n, h_in, w_in, h_out,
+                w_out, c);
+    const int64_t total = (int64_t)n * h_out * w_out;
+    hipLaunchKernelGGL(warp_affine_kernel<true>, dim3(grid_for(total)), dim3(kThreads), 0, asr_stream(stream),
                        src, dst, transforms, n, src_batched, tf_batched, h_in, w_in, h_out, w_out, c);
     ASR_LAUNCH_CHECK();
     return ASR_OK;

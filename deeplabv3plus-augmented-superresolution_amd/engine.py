@@ -1,4 +1,4 @@
-"""Device execution plan for the DeepLabV3+ (Xception-65, OS16) forward pass.
+"""Device execution plan for the DeepLabV3+ forward pass (Xception-65 OS16; MobileNetV2 OS8).
 
 The reference runs 147 Keras layers as separate library kernels with an HBM round trip each
 (``model.predict``, superresolution_scripts/augmentation_utils.py:76).  Here the graph of
@@ -77,7 +77,7 @@ def _same_pad(in_size, k_eff, stride):
 class DeeplabEngine:
     """Folded / packed parameters on the device + per-(batch, H, W) launch plans."""
 
-    def __init__(self, weights: dict, classes=21, device=None, precision=None):
+    def __init__(self, weights: dict, classes=21, device=None, precision=None, backbone="xception", alpha=1.0):
         """precision: 'f32' = v_mfma_f32_32x32x2_f32 everywhere (exact f32 fmaf chains);
         'f16x3' = split-f16 MFMA (hi*hi + hi*lo + lo*hi, f32 accumulate; f32-grade results, ~2.4x faster)
         for the pointwise GEMMs with more than 64 output channels.  Default: $ASR_PRECISION or 'f16x3'."""
@@ -85,6 +85,11 @@ class DeeplabEngine:
         self.precision = precision or os.environ.get("ASR_PRECISION", "f16x3")
         if self.precision not in ("f32", "f16x3"):
             raise ValueError(f"precision must be 'f32' or 'f16x3', got {self.precision!r}")
+        if backbone not in ("xception", "mobilenet"):
+            raise ValueError("Backbone must be either xception or mobilenet")
+        self.backbone = backbone
+        self.alpha = alpha
+        self.output_stride = 4 if backbone == "xception" else 8      # input size / logits size
         self.classes = classes
         self.logits_name = "logits_semantic" if "logits_semantic/kernel" in weights else "custom_logits_semantic"
         self.p = {}
@@ -115,7 +120,29 @@ class DeeplabEngine:
         self._put_dw(prefix + "_depthwise", prefix + "_depthwise_BN", eps)
         self._put_conv(prefix + "_pointwise", prefix + "_pointwise_BN", eps)
 
+    def _upload_mobilenet(self, weights):
+        """model.py:308-379, 426-461: BN folded into every conv / depthwise; ReLU6 lives in the kernels' epilogues."""
+        self._w = weights
+        e3, e5 = W.XCEPTION_BN_EPS, W.HEAD_BN_EPS
+        k, b = W.fold_conv_bn(weights, "Conv", "Conv_BN", e3)         # HWIO for the direct stem kernel
+        self.p["Conv"] = dict(w=self._dev(k), b=self._dev(b), k=k.shape[0], n=k.shape[1])
+        self._put_dw("expanded_conv_depthwise", "expanded_conv_depthwise_BN", e3)
+        self._put_conv("expanded_conv_project", "expanded_conv_project_BN", e3)
+        for bid, *_ in W.mobilenet_blocks(self.alpha):
+            p = f"expanded_conv_{bid}_"
+            self._put_conv(p + "expand", p + "expand_BN", e3)
+            self._put_dw(p + "depthwise", p + "depthwise_BN", e3)
+            self._put_conv(p + "project", p + "project_BN", e3)
+        self._put_conv("image_pooling", "image_pooling_BN", e5)
+        self._put_conv("aspp0", "aspp0_BN", e5)
+        self._put_conv("concat_projection", "concat_projection_BN", e5)
+        self._put_conv(self.logits_name, None, None)
+        torch.cuda.synchronize(self.device)
+        del self._w
+
     def _upload(self, weights):
+        if self.backbone == "mobilenet":
+            return self._upload_mobilenet(weights)
         self._w = weights
         e3, e5 = W.XCEPTION_BN_EPS, W.HEAD_BN_EPS
         # entry_flow_conv1_1 keeps its HWIO layout for the direct kernel
@@ -180,15 +207,19 @@ class DeeplabEngine:
                 label=f"{name} M={m} K={p['k']} N={p['n']}", out=out)
             return out
 
-        def dw(x, name, stride, rate, pre_relu, post_relu):
+        def dw(x, name, stride, rate, pre_relu, post_relu, tf_same=False):
             p = self.p[name]
             b, h, w, c = x.shape
             pad = rate                      # stride 1 'same' and the explicit ZeroPadding2D both give `rate`
             ho, wo = (h, w) if stride == 1 else ((h + 2 * pad - (2 * rate + 1)) // stride + 1,
                                                  (w + 2 * pad - (2 * rate + 1)) // stride + 1)
+            pad_t = pad_l = pad
+            if tf_same and stride > 1:      # Keras padding='same' on a strided conv: TF SAME puts the odd pixel after
+                ho, pad_t = _same_pad(h, 2 * rate + 1, stride)
+                wo, pad_l = _same_pad(w, 2 * rate + 1, stride)
             out = new((b, ho, wo, c))
             add("asr_dwconv3x3_nhwc_f32",
-                (x.ptr, p["w"].data_ptr(), p["b"].data_ptr(), out.ptr, b, h, w, c, stride, rate, pad, pad, ho, wo, x.ld,
+                (x.ptr, p["w"].data_ptr(), p["b"].data_ptr(), out.ptr, b, h, w, c, stride, rate, pad_t, pad_l, ho, wo, x.ld,
                  out.ld, int(pre_relu), int(post_relu), 0),
                 "dw", 18.0 * b * ho * wo * c, 4.0 * (b * h * w * c + b * ho * wo * c + 10 * c),
                 label=f"{name} {h}x{w}x{c} s{stride} r{rate}", out=out)
@@ -218,10 +249,51 @@ class DeeplabEngine:
                 release(x)
             return (r3, r2) if return_skip else r3
 
-        # ---- entry flow (model.py:149-170) ----
         x_in = new((B, H, Wd, 3), pad=False)
         h1, pt = _same_pad(H, 3, 2)
         w1, pl = _same_pad(Wd, 3, 2)
+        if self.backbone == "mobilenet":
+            # ---- EntryBlockMobile (model.py:308-337) ----
+            p = self.p["Conv"]
+            c0 = p["n"]
+            a1 = new((B, h1, w1, c0))
+            add("asr_conv3x3_direct_f32", (x_in.ptr, p["w"].data_ptr(), p["b"].data_ptr(), a1.ptr, B, H, Wd, 3, c0, 2, pt, pl,
+                                           h1, w1, 3, a1.ld, 2), "conv", 2.0 * B * h1 * w1 * 27 * c0,
+                4.0 * (B * H * Wd * 3 + B * h1 * w1 * c0), label="Conv", out=a1)
+            t = dw(a1, "expanded_conv_depthwise", 1, 1, False, 2)
+            release(a1)
+            x = pw(t, "expanded_conv_project")
+            release(t)
+            # ---- MobileNet_Backbone_Encoder (model.py:339-379): 16 inverted residual blocks ----
+            for bid, _cin, _cout, stride, rate, skip in W.mobilenet_blocks(self.alpha):
+                pfx = f"expanded_conv_{bid}_"
+                e = pw(x, pfx + "expand", relu=2)
+                d = dw(e, pfx + "depthwise", stride, rate, False, 2, tf_same=True)
+                release(e)
+                y = pw(d, pfx + "project", res=x if skip else None)
+                release(d)
+                release(x)
+                x = y
+            # ---- ASPP without atrous branches (model.py:192-210, 224-231); no decoder (model.py:94-101) ----
+            b, fh, fw, fc = x.shape
+            cat = new((b, fh, fw, 512))
+            pooled = new((b, 1, 1, fc), pad=False)
+            add("asr_gap_f32", (x.ptr, pooled.ptr, b, fh * fw, fc, x.ld), "misc", b * fh * fw * fc, 4.0 * b * fh * fw * fc,
+                label="gap", out=pooled)
+            pp = pw(pooled, "image_pooling", relu=True)
+            add("asr_resize_bilinear_f32", (pp.ptr, cat.ptr, b, 1, 1, 256, fh, fw, pp.ld, cat.ld), "misc", 0,
+                4.0 * b * fh * fw * 256)
+            release(pooled)
+            release(pp)
+            pw(x, "aspp0", out=cat, out_off=256, relu=True)
+            release(x)
+            x = pw(cat, "concat_projection", relu=True)
+            release(cat)
+            logits = pw(x, self.logits_name, pad_out=False)
+            release(x)
+            return dict(steps=steps, outs=outs, pool=pool, x_in=x_in, logits=logits, pool_bytes=pool.total_bytes,
+                        out_shape=(B, fh, fw, self.classes))
+        # ---- entry flow (model.py:149-170) ----
         a1 = new((B, h1, w1, 32))
         p = self.p["entry_flow_conv1_1"]
         add("asr_conv3x3_direct_f32", (x_in.ptr, p["w"].data_ptr(), p["b"].data_ptr(), a1.ptr, B, H, Wd, 3, 32, 2, pt, pl,
@@ -297,8 +369,9 @@ class DeeplabEngine:
     def plan(self, B, H, Wd):
         key = (B, H, Wd)
         if key not in self._plans:
-            if H % 16 or Wd % 16:
-                raise ValueError(f"input size must be a multiple of 16 for OS16 (got {H}x{Wd})")
+            mult = 16 if self.backbone == "xception" else 8
+            if H % mult or Wd % mult:
+                raise ValueError(f"input size must be a multiple of {mult} for the {self.backbone} backbone (got {H}x{Wd})")
             self._plans[key] = self._build_plan(B, H, Wd)
         return self._plans[key]
 

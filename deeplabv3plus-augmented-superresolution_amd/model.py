@@ -1,10 +1,10 @@
 """``DeeplabV3Plus`` with the reference's constructor / ``build_model`` / ``predict`` surface
 (model.py:16-147), executing on hand-written gfx950 kernels through ``engine.DeeplabEngine``.
 
-Scope: Xception backbone, OS=16, ``classes`` logits, ``final_upsample`` on or
-off, ``last_activation`` None.  The MobileNetV2 backbone, OS=8, the ``only_*`` decoders and
-``reshape_outputs`` are validated like the reference and then rejected with
-NotImplementedError (not on the hot path).
+Scope: Xception backbone at OS=16 and the MobileNetV2 backbone (always OS=8,
+model.py:53-55), ``classes`` logits, ``final_upsample`` on or off, ``last_activation`` None / softmax /
+sigmoid.  Xception at OS=8, the ``only_*`` decoders and ``reshape_outputs`` are validated like the reference
+and then rejected with NotImplementedError (not on the hot path).
 """
 from __future__ import annotations
 
@@ -28,10 +28,10 @@ class DeeplabV3Plus:
             raise ValueError("The last_activation parameter must be either None, softmax or sigmoid")
         if not (backbone in {"xception", "mobilenet"}):
             raise ValueError("Backbone must be either xception or mobilenet")
-        if backbone != "xception":
-            raise NotImplementedError("only the Xception backbone is on the accelerated path")
-        if OS != 16:
-            raise NotImplementedError("only OS=16 is on the accelerated path (model.py:48-52)")
+        if backbone == "xception" and OS != 16:
+            raise NotImplementedError("only OS=16 is on the accelerated path for Xception (model.py:48-52)")
+        if backbone == "mobilenet":
+            OS = 8                                     # model.py:53-55: OS is set to 8 for the mobilenet backbone
         if reshape_outputs:
             raise NotImplementedError("reshape_outputs is not on the accelerated path")
         if input_tensor is not None:
@@ -50,7 +50,7 @@ class DeeplabV3Plus:
 
     def build_model(self, only_DCNN_output=False, only_ASPP_output=False, first_upsample_size=(128, 128),
                     final_upsample=True, final_class_prediction=True):
-        if only_DCNN_output is True and only_ASPP_output is True:
+        if self.backbone == "xception" and only_DCNN_output is True and only_ASPP_output is True:
             raise ValueError("Both only_DCNN_output and only_ASPP_output cannot be True at the same time")
         if only_DCNN_output or only_ASPP_output or not final_class_prediction:
             raise NotImplementedError("alternative decoders are not on the accelerated path")
@@ -58,22 +58,24 @@ class DeeplabV3Plus:
             params = W.load_weights(self.weights_path)          # local file only (never the URL of model.py:9)
         else:
             # The pretrained .h5 is a network download (model.py:134-143): unavailable offline.
-            params = W.make_synthetic_weights(self.synthetic_seed, self.classes)
+            params = W.make_synthetic_weights(self.synthetic_seed, self.classes, backbone=self.backbone, alpha=self.alpha)
         return DeeplabModel(params, self.input_shape, self.classes, final_upsample, self.last_activation,
-                            precision=self.precision)
+                            precision=self.precision, backbone=self.backbone, alpha=self.alpha)
 
 
 class DeeplabModel:
     """What ``build_model`` returns: only ``predict`` (and ``predict_device``) are used by callers
     (augmentation_utils.py:76)."""
 
-    def __init__(self, params, input_shape, classes, final_upsample, last_activation, precision=None):
+    def __init__(self, params, input_shape, classes, final_upsample, last_activation, precision=None,
+                 backbone="xception", alpha=1.0):
         self.input_shape = tuple(input_shape)
         self.classes = classes
         self.final_upsample = final_upsample
         self.last_activation = last_activation
-        self.name = "DLV3Plus-xception-OS16"
-        self.engine = DeeplabEngine(params, classes, precision=precision)
+        self.backbone = backbone
+        self.name = f"DLV3Plus-{backbone}-OS{16 if backbone == 'xception' else 8}"      # model.py:71
+        self.engine = DeeplabEngine(params, classes, precision=precision, backbone=backbone, alpha=alpha)
         self.precision = self.engine.precision
         self.device = self.engine.device
 

@@ -31,8 +31,11 @@ def to_device(a, dtype=f32, device=None):
 # ---------------------------------------------------------------------------------------------
 # warps
 # ---------------------------------------------------------------------------------------------
-def warp_affine(src, transforms, out_hw=None, n=None):
-    """src [N,H,W,C] or [H,W,C] (shared), transforms [N,8] or [8] (shared) -> [N,Ho,Wo,C]."""
+def warp_affine(src, transforms, out_hw=None, n=None, interpolation="bilinear"):
+    """src [N,H,W,C] or [H,W,C] (shared), transforms [N,8] or [8] (shared) -> [N,Ho,Wo,C]; interpolation
+    "bilinear" or "nearest" (ImageProjectiveTransformV3, zero fill)."""
+    if interpolation not in ("bilinear", "nearest"):
+        raise AsrError("warp_affine: interpolation must be 'bilinear' or 'nearest'")
     src_b = src.dim() == 4
     tf_b = transforms.dim() == 2
     if src_b:
@@ -48,8 +51,8 @@ def warp_affine(src, transforms, out_hw=None, n=None):
         raise AsrError("warp_affine: transforms must have 8 coefficients")
     ho, wo = out_hw or (h, w)
     dst = torch.empty((n, ho, wo, c), dtype=f32, device=src.device)
-    call("asr_warp_affine_f32", ptr(src), ptr(dst), ptr(transforms), n, int(src_b), int(tf_b), h, w, ho, wo, c,
-         stream_ptr())
+    call("asr_warp_affine_f32" if interpolation == "bilinear" else "asr_warp_affine_nearest_f32", ptr(src), ptr(dst),
+         ptr(transforms), n, int(src_b), int(tf_b), h, w, ho, wo, c, stream_ptr())
     return dst
 
 
@@ -197,6 +200,17 @@ def sr_solve(x, y, rot_tf, trans_tf, inv_rot_tf, inv_trans_tf, alphas, lambdas, 
              C.c_size_t(ws_bytes), b, n, H, W, h, w, float(lambdas[0]), float(lambdas[1]), float(lambdas[2]),
              float(lambdas[3]), C.byref(cfg), stream_ptr())
     return x, terms
+
+
+def class_counts(truth, pred, segments=1):
+    """int32 label tensors -> int64 [segments, 3, 256]: per label |truth|, |pred|, |truth & pred| (Mean_IOU)."""
+    per = truth.numel() // segments
+    if per * segments != truth.numel() or pred.numel() != truth.numel():
+        raise AsrError("class_counts: truth / pred sizes do not split into equal segments")
+    out = torch.empty((segments, 3, 256), dtype=torch.int64, device=truth.device)
+    call("asr_class_counts_i32", ptr(truth, torch.int32), ptr(pred, torch.int32), ptr(out, torch.int64), per, segments,
+         stream_ptr())
+    return out
 
 
 def realign(y, trans_tf, rot_tf, out_hw, mode):

@@ -83,13 +83,31 @@ def single_class_IOU(y_true, y_pred, class_id, include_bg):
     return iou_from_counts(counts, include_bg)
 
 
+def mean_iou_from_counts(counts):
+    """counts [3, 256] (ops.class_counts) -> Mean_IOU (utils.py:151-177): mean over the labels present in the ground
+    truth, void (255) removed, of inter / union; like tf.reduce_mean of an empty list, NaN when no label qualifies."""
+    c = np.asarray(counts, dtype=np.int64)
+    labels = [l for l in range(255) if c[0, l] > 0]
+    if not labels:
+        return float("nan")
+    ious = [np.float64(c[2, l]) / np.float64(c[0, l] + c[1, l] - c[2, l]) for l in labels]
+    return float(np.mean(ious))
+
+
+def Mean_IOU(y_true, y_pred):
+    dev = _lib.require_gpu()
+    counts = ops.class_counts(_as_label_tensor(y_true, dev), _as_label_tensor(y_pred, dev)).cpu().numpy()[0]
+    return mean_iou_from_counts(counts)
+
+
 def compute_IoU(true_image, image, img_size=(512, 512), class_id=None, include_bg=False):
-    """Single-class IoU of two label maps (utils.py:207-230).  Void (255) pixels are NOT excluded,
-    exactly like the reference."""
-    if class_id is None:
-        raise NotImplementedError("multi-class Mean_IOU (utils.py:151-177) is not on the accelerated path")
+    """IoU of two label maps (utils.py:207-230): single class (optionally with background) when class_id is given,
+    otherwise the multi-class Mean_IOU.  Void (255) pixels are NOT excluded from the single-class form, exactly
+    like the reference."""
     n = img_size[0] * img_size[1]
     size = lambda a: a.numel() if isinstance(a, torch.Tensor) else np.asarray(a).size
     if size(true_image) != n or size(image) != n:
         raise ValueError(f"expected {n} pixels, got {size(true_image)} and {size(image)}")
+    if class_id is None:
+        return Mean_IOU(true_image, image)
     return single_class_IOU(true_image, image, class_id, include_bg)

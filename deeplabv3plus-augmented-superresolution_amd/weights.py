@@ -29,8 +29,76 @@ def xception_blocks():
     return blocks
 
 
-def layer_inventory(classes=21):
+def make_divisible(value, divisor, min_value=None):
+    """model.py:544-556."""
+    if min_value is None:
+        min_value = divisor
+    new_v = max(min_value, int(value + divisor / 2) // divisor * divisor)
+    if new_v < 0.9 * value:
+        new_v += divisor
+    return new_v
+
+
+def mobilenet_blocks(alpha=1.0):
+    """MobileNet_Backbone_Encoder (model.py:339-379): (block_id, in_channels, out_channels, stride, rate, skip)
+    of the 16 inverted residual blocks (expansion factor 6, OS = 8: strides of blocks 6 and 13 replaced by dilation)."""
+    spec = [(1, 24, 2, 1, False), (2, 24, 1, 1, True),
+            (3, 32, 2, 1, False), (4, 32, 1, 1, True), (5, 32, 1, 1, True),
+            (6, 64, 1, 1, False), (7, 64, 1, 2, True), (8, 64, 1, 2, True), (9, 64, 1, 2, True),
+            (10, 96, 1, 2, False), (11, 96, 1, 2, True), (12, 96, 1, 2, True),
+            (13, 160, 1, 2, False), (14, 160, 1, 4, True), (15, 160, 1, 4, True),
+            (16, 320, 1, 4, False)]
+    cin = make_divisible(int(16 * alpha), 8)
+    out = []
+    for bid, filters, stride, rate, skip in spec:
+        cout = make_divisible(int(filters * alpha), 8)
+        out.append((bid, cin, cout, stride, rate, skip))
+        cin = cout
+    return out
+
+
+def mobilenet_inventory(classes=21, alpha=1.0):
+    """Layers of the MobileNetV2 variant (model.py:308-337 EntryBlockMobile, :426-461 _inverted_res_block,
+    :192-233 ASPP without the atrous branches, :296-306 logits), Keras names."""
+    inv = []
+
+    def conv(name, kh, cin, cout, bias=False):
+        inv.append(("conv", name, dict(kh=kh, cin=cin, cout=cout, bias=bias)))
+
+    def bn(name, c, eps):
+        inv.append(("bn", name, dict(c=c, eps=eps)))
+
+    first = make_divisible(32 * alpha, 8)
+    conv("Conv", 3, 3, first)
+    bn("Conv_BN", first, XCEPTION_BN_EPS)
+    inv.append(("dw", "expanded_conv_depthwise", dict(c=first)))
+    bn("expanded_conv_depthwise_BN", first, XCEPTION_BN_EPS)
+    c0 = make_divisible(int(16 * alpha), 8)
+    conv("expanded_conv_project", 1, first, c0)
+    bn("expanded_conv_project_BN", c0, XCEPTION_BN_EPS)
+    for bid, cin, cout, _stride, _rate, _skip in mobilenet_blocks(alpha):
+        p = f"expanded_conv_{bid}_"
+        conv(p + "expand", 1, cin, 6 * cin)
+        bn(p + "expand_BN", 6 * cin, XCEPTION_BN_EPS)
+        inv.append(("dw", p + "depthwise", dict(c=6 * cin)))
+        bn(p + "depthwise_BN", 6 * cin, XCEPTION_BN_EPS)
+        conv(p + "project", 1, 6 * cin, cout)
+        bn(p + "project_BN", cout, XCEPTION_BN_EPS)
+    c_enc = mobilenet_blocks(alpha)[-1][2]
+    conv("image_pooling", 1, c_enc, 256)
+    bn("image_pooling_BN", 256, HEAD_BN_EPS)
+    conv("aspp0", 1, c_enc, 256)
+    bn("aspp0_BN", 256, HEAD_BN_EPS)
+    conv("concat_projection", 1, 512, 256)
+    bn("concat_projection_BN", 256, HEAD_BN_EPS)
+    conv("logits_semantic" if classes == 21 else "custom_logits_semantic", 1, 256, classes, bias=True)
+    return inv
+
+
+def layer_inventory(classes=21, backbone="xception", alpha=1.0):
     """Ordered list of (kind, name, shape-info dict).  kinds: conv, dw, bn."""
+    if backbone == "mobilenet":
+        return mobilenet_inventory(classes, alpha)
     inv = []
 
     def conv(name, kh, cin, cout, bias=False):
@@ -73,9 +141,9 @@ def layer_inventory(classes=21):
     return inv
 
 
-def count_params(classes=21):
+def count_params(classes=21, backbone="xception", alpha=1.0):
     n = 0
-    for kind, _name, d in layer_inventory(classes):
+    for kind, _name, d in layer_inventory(classes, backbone, alpha):
         if kind == "conv":
             n += d["kh"] * d["kh"] * d["cin"] * d["cout"] + (d["cout"] if d["bias"] else 0)
         elif kind == "dw":
@@ -85,14 +153,18 @@ def count_params(classes=21):
     return n
 
 
-def make_synthetic_weights(seed=1234, classes=21):
+def make_synthetic_weights(seed=1234, classes=21, backbone="xception", alpha=1.0):
     """Seeded random parameters with variance-preserving scales so that activations stay O(1)
     through the 65+ layers (He-style std for kernels that follow a ReLU, 1/sqrt(fan_in)
     otherwise; BN statistics near identity; residual branches damped)."""
     rng = np.random.default_rng(seed)
     w = {}
-    inv = layer_inventory(classes)
+    inv = layer_inventory(classes, backbone, alpha)
     relu_before = set()        # conv layers whose input passed through a ReLU
+    if backbone == "mobilenet":
+        relu_before |= {"expanded_conv_depthwise", "expanded_conv_project"}
+        for bid, *_ in mobilenet_blocks(alpha):
+            relu_before |= {f"expanded_conv_{bid}_depthwise", f"expanded_conv_{bid}_project"}
     for prefix, _cin, _f, _skip, _s, _r, depth_act in xception_blocks():
         for i in range(3):
             p = f"{prefix}_separable_conv{i + 1}"
@@ -102,6 +174,7 @@ def make_synthetic_weights(seed=1234, classes=21):
     relu_before |= {"entry_flow_conv1_2", "aspp0", "image_pooling", "concat_projection", "logits_semantic",
                     "custom_logits_semantic"}
     damped = {f"middle_flow_unit_{i + 1}_separable_conv3_pointwise_BN" for i in range(16)}
+    damped |= {f"expanded_conv_{bid}_project_BN" for bid, _ci, _co, _s, _r, skip in mobilenet_blocks(alpha) if skip}
     for kind, name, d in inv:
         if kind == "conv":
             fan_in = d["kh"] * d["kh"] * d["cin"]

@@ -57,6 +57,11 @@ const char* asr_target_arch(void);
 int asr_warp_affine_f32(const float* src, float* dst, const float* transforms, int n, int src_batched,
                         int tf_batched, int h_in, int w_in, int h_out, int w_out, int c, asr_stream_t stream);
 
+/* The same pass with interpolation "NEAREST" (tfa.image.rotate / translate of the label maps,
+ * check_robustness.py:45-50): dst = src(round(in_y), round(in_x)) with std::round, 0 outside. */
+int asr_warp_affine_nearest_f32(const float* src, float* dst, const float* transforms, int n, int src_batched,
+                        int tf_batched, int h_in, int w_in, int h_out, int w_out, int c, asr_stream_t stream);
+
 /* copies[i] = translate(rotate(image, rot_tf[i]), trans_tf[i]) -- tile + two bilinear resamplings
  * fused (superresolution_scripts/augmentation_utils.py:12-25 create_augmented_copies; :46-54
  * chunked variant).  image [h,w,c] (c = 1 or 3), copies [n,h,w,c], rot_tf / trans_tf [n,8]. */
@@ -210,6 +215,12 @@ int asr_threshold_f32(const float* image, const float* th_mask, float* minmax_ws
 int asr_iou_counts_i32(const int32_t* truth, const int32_t* pred, int64_t* counts, int64_t per_segment, int segments,
                        int class_id, int include_bg, asr_stream_t stream);
 
+/* Per-label pixel counts for the multi-class Mean_IOU (utils.py:151-177, compute_IoU(class_id=None)):
+ * counts[seg][0][l] = |truth == l|, counts[seg][1][l] = |pred == l|, counts[seg][2][l] = |truth == l and pred == l|,
+ * l = 0..255 (int64, zeroed by the call); IoU_l = c2 / (c0 + c1 - c2). */
+int asr_class_counts_i32(const int32_t* truth, const int32_t* pred, int64_t* counts, int64_t per_segment, int segments,
+                         asr_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * DeepLabV3+ (Xception-65, OS16) layers -- model.py.  BatchNorm is folded by the caller.
  * ------------------------------------------------------------------------------------------ */
@@ -224,7 +235,8 @@ int asr_pwconv_pack_weights_f32(const float* w_kn, float* w_packed, int k, int n
  * Conv2D + BatchNormalization (+ ReLU / Add) group of model.py (:195-231, :244-247, :303-304,
  * :403-417, :500-506).  sub_stride > 1: rows are gathered at (b, s*oy, s*ox) of an
  * h_in x w_in map -- the stride-2 1x1 shortcut of _conv2d_same (model.py:529-541).
- * k % 4 == 0, ldx % 4 == 0. */
+ * relu: 0 = linear, 1 = ReLU, 2 = ReLU6 (the expand convs of _inverted_res_block, model.py:434-440; the same
+ * encoding is used by every `relu` / `post_relu` argument below).  k % 4 == 0, ldx % 4 == 0. */
 int asr_pwconv_mfma_f32(const float* x, const float* w_packed, const float* bias, const float* residual, float* y,
                         int64_t m, int k, int n, int ldx, int ldy, int ldres, int relu, int sub_stride, int h_in,
                         int w_in, asr_stream_t stream);
@@ -258,7 +270,8 @@ int asr_conv3x3_direct_f32(const float* x, const float* w, const float* bias, fl
                            int ldy, int relu, asr_stream_t stream);
 
 /* DepthwiseConv2D 3x3 (+ ZeroPadding2D, folded BN, ReLU before and/or after): the depthwise half
- * of _SepConv_BN, model.py:478-495.  w [3,3,c] with the BN scale folded, bias [c].
+ * of _SepConv_BN, model.py:478-495, and of _inverted_res_block, model.py:442-449 (post_relu = 2: ReLU6).
+ * w [3,3,c] with the BN scale folded, bias [c].
  * mode: 0 = auto, 1 = direct, 2 = register-window streaming, 3 = LDS-tiled, 4 = flat streaming (testing / A-B runs). */
 int asr_dwconv3x3_nhwc_f32(const float* x, const float* w, const float* bias, float* y, int batch, int h_in,
                            int w_in, int c, int stride, int rate, int pad_top, int pad_left, int h_out, int w_out,

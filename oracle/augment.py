@@ -111,3 +111,17 @@ def compute_IoU(true_image, image, img_size=(512, 512), class_id=None, include_b
     if class_id is None:
         raise NotImplementedError("oracle restates the single-class mode only")
     return single_class_IOU(t, p, class_id, include_bg)
+
+
+def Mean_IOU(y_true, y_pred):
+    """utils.py:151-177: mean over the labels PRESENT IN THE GROUND TRUTH (void 255 removed) of
+    |true == i & pred == i| / |true == i | pred == i|."""
+    t = np.asarray(y_true).astype(np.int64).reshape(-1)
+    p = np.asarray(y_pred).astype(np.int64).reshape(-1)
+    ious = []
+    for i in np.unique(t):
+        if i == 255:
+            continue
+        tl, pl = t == i, p == i
+        ious.append(np.sum(tl & pl) / np.sum(tl | pl))
+    return float(np.mean(ious)) if ious else float("nan")

@@ -1,9 +1,10 @@
 """Layer-by-layer, UNFUSED torch-CPU float32 restatement of the reference's DeepLabV3+
-(Xception-65, OS16) inference graph.  TEST INFRASTRUCTURE ONLY.
+(Xception-65, OS16; and the MobileNetV2 variant, OS8) inference graph.  TEST INFRASTRUCTURE ONLY.
 
 Follows model.py:64-147 (build_model), :149-190 (entry/middle/exit flow), :192-233 (ASPP),
 :235-259 (Decoder), :296-306 (logits), :381-424 (_Xception_block), :463-508 (_SepConv_BN),
-:510-541 (_conv2d_same) of the reference.  Keras layer semantics restated from keras==2.7.0:
+:510-541 (_conv2d_same); MobileNetV2: :308-337 (EntryBlockMobile), :339-379 (MobileNet_Backbone_Encoder),
+:426-461 (_inverted_res_block) of the reference.  Keras layer semantics restated from keras==2.7.0:
 Conv2D/DepthwiseConv2D 'same' padding (pad_total = max((ceil(in/s)-1)*s + k_eff - in, 0),
 before = pad_total // 2), BatchNormalization inference y = gamma*(x-mean)/sqrt(var+eps)+beta,
 Resizing(bilinear) = tf.image.resize half-pixel, GlobalAveragePooling2D(keepdims=True).
@@ -32,10 +33,11 @@ class OracleDeeplabV3Plus:
     """Xception backbone, OS=16 only (model.py:48-52: entry_block3_stride 2, middle rate 1,
     exit rates (1,2), atrous rates (6,12,18))."""
 
-    def __init__(self, weights: dict, classes=21, last_activation=None):
+    def __init__(self, weights: dict, classes=21, last_activation=None, backbone="xception"):
         self.w = {k: torch.as_tensor(np.asarray(v, dtype=np.float32)) for k, v in weights.items()}
         self.classes = classes
         self.last_activation = last_activation
+        self.backbone = backbone
 
     # ---- Keras layers (NCHW inside) ---------------------------------------------------
     def conv(self, x, name, stride=1, padding="same", rate=1):
@@ -115,11 +117,56 @@ class OracleDeeplabV3Plus:
             out = r
         return (out, skip) if return_skip else out
 
+    # ---- model.py:426-461 ---------------------------------------------------------------
+    def inverted_res_block(self, inputs, block_id, stride, rate, skip_connection):
+        p = f"expanded_conv_{block_id}_"
+        x = F.relu6(self.bn(self.conv(inputs, p + "expand"), p + "expand_BN"))
+        x = F.relu6(self.bn(self.dwconv(x, p + "depthwise", stride=stride, rate=rate), p + "depthwise_BN"))
+        x = self.bn(self.conv(x, p + "project"), p + "project_BN")
+        return inputs + x if skip_connection else x
+
+    def forward_mobilenet(self, x, stages):
+        """model.py:94-101, 308-379: entry block, 16 inverted residual blocks (OS 8), ASPP = image pooling + aspp0."""
+        x = F.relu6(self.bn(self.conv(x, "Conv", stride=2), "Conv_BN"))
+        x = F.relu6(self.bn(self.dwconv(x, "expanded_conv_depthwise"), "expanded_conv_depthwise_BN"))
+        x = self.bn(self.conv(x, "expanded_conv_project"), "expanded_conv_project_BN")
+        stages["entry"] = x
+        spec = [(1, 2, 1, False), (2, 1, 1, True), (3, 2, 1, False), (4, 1, 1, True), (5, 1, 1, True), (6, 1, 1, False),
+                (7, 1, 2, True), (8, 1, 2, True), (9, 1, 2, True), (10, 1, 2, False), (11, 1, 2, True), (12, 1, 2, True),
+                (13, 1, 2, False), (14, 1, 4, True), (15, 1, 4, True), (16, 1, 4, False)]
+        for bid, stride, rate, skip in spec:
+            x = self.inverted_res_block(x, bid, stride, rate, skip)
+            if bid in (2, 5, 12):
+                stages[f"block{bid}"] = x
+        stages["exit"] = x
+        fh, fw = x.shape[2:]
+        pool = x.mean(dim=(2, 3), keepdim=True)
+        pool = F.relu(self.bn(self.conv(pool, "image_pooling"), "image_pooling_BN", 1e-5))
+        pool = self.resize(pool, (fh, fw))
+        b0 = F.relu(self.bn(self.conv(x, "aspp0"), "aspp0_BN", 1e-5))
+        x = torch.cat([pool, b0], dim=1)
+        x = F.relu(self.bn(self.conv(x, "concat_projection"), "concat_projection_BN", 1e-5))
+        stages["aspp"] = x
+        return x
+
     # ---- model.py:64-147 ------------------------------------------------------------------
     def forward(self, images_nhwc, final_upsample=False, return_stages=False):
         x = torch.as_tensor(np.asarray(images_nhwc, dtype=np.float32)).permute(0, 3, 1, 2).contiguous()
         in_hw = x.shape[2:]
         stages = {}
+        if self.backbone == "mobilenet":
+            x = self.forward_mobilenet(x, stages)
+            x = self.conv(x, "logits_semantic" if "logits_semantic/kernel" in self.w else "custom_logits_semantic")
+            if final_upsample:
+                x = self.resize(x, in_hw)
+            if self.last_activation == "softmax":
+                x = torch.softmax(x, dim=1)
+            elif self.last_activation == "sigmoid":
+                x = torch.sigmoid(x)
+            out = x.permute(0, 2, 3, 1).contiguous().numpy()
+            if return_stages:
+                return out, {k: v.permute(0, 2, 3, 1).contiguous().numpy() for k, v in stages.items()}
+            return out
         # entry flow (model.py:149-170)
         x = F.relu(self.bn(self.conv(x, "entry_flow_conv1_1", stride=2), "entry_flow_conv1_1_BN"))
         stages["conv1_1"] = x

@@ -78,8 +78,10 @@ def invert_transforms(transforms):
 # --------------------------------------------------------------------------------------
 # ImageProjectiveTransformV3, BILINEAR, CONSTANT fill 0
 # --------------------------------------------------------------------------------------
-def projective_transform(images, transforms, output_shape=None):
+def projective_transform(images, transforms, output_shape=None, interpolation="bilinear"):
     """images [N,H,W,C] f32, transforms [N,8] (or [1,8]) f32 -> [N,Ho,Wo,C] f32.
+    interpolation="nearest" (check_robustness.py:45-50 on the label maps): TF nearest_interpolation reads
+    I(round(in_y), round(in_x)) with std::round (half away from zero), 0 outside.
 
     TF image_ops.h ProjectiveGenerator::operator() + bilinear_interpolation +
     read_with_fill_value: for output (x=col, y=row)
@@ -100,11 +102,18 @@ def projective_transform(images, transforms, output_shape=None):
     proj = t[:, 6] * xs + t[:, 7] * ys + 1.0
     in_x = (t[:, 0] * xs + t[:, 1] * ys + t[:, 2]) / proj
     in_y = (t[:, 3] * xs + t[:, 4] * ys + t[:, 5]) / proj
+    flat = img.reshape(n, h * w, c)
+    if interpolation == "nearest":
+        rnd = lambda v: torch.sign(v) * torch.floor(torch.abs(v) + 0.5)          # std::round
+        yy, xx = rnd(in_y), rnd(in_x)
+        valid = (yy >= 0) & (yy < h) & (xx >= 0) & (xx < w) & (proj != 0)
+        idx = (yy.clamp(0, h - 1).to(torch.int64) * w + xx.clamp(0, w - 1).to(torch.int64))
+        v = torch.gather(flat, 1, idx.reshape(n, ho * wo, 1).expand(n, ho * wo, c)).reshape(n, ho, wo, c)
+        return v * valid.reshape(n, ho, wo, 1).to(F32)
     x_f = torch.floor(in_x)
     y_f = torch.floor(in_y)
     x_c = x_f + 1.0
     y_c = y_f + 1.0
-    flat = img.reshape(n, h * w, c)
 
     def read(yy, xx):
         valid = (yy >= 0) & (yy < h) & (xx >= 0) & (xx < w)
@@ -132,15 +141,15 @@ def projective_transform_grad(grad, transforms, input_hw):
     return projective_transform(grad, invert_transforms(np.asarray(transforms)), output_shape=input_hw)
 
 
-def rotate(images, angles):
-    """tfa.image.rotate(images, angles, interpolation='bilinear') (augmentation_utils.py:22)."""
+def rotate(images, angles, interpolation="bilinear"):
+    """tfa.image.rotate(images, angles, interpolation=...) (augmentation_utils.py:22, check_robustness.py:46-47)."""
     n, h, w, _ = images.shape
-    return projective_transform(images, angles_to_projective_transforms(angles, h, w))
+    return projective_transform(images, angles_to_projective_transforms(angles, h, w), interpolation=interpolation)
 
 
-def translate(images, translations):
-    """tfa.image.translate(images, shifts, interpolation='bilinear') (augmentation_utils.py:24)."""
-    return projective_transform(images, translations_to_projective_transforms(translations))
+def translate(images, translations, interpolation="bilinear"):
+    """tfa.image.translate(images, shifts, interpolation=...) (augmentation_utils.py:24, check_robustness.py:48-49)."""
+    return projective_transform(images, translations_to_projective_transforms(translations), interpolation=interpolation)
 
 
 # --------------------------------------------------------------------------------------

@@ -24,6 +24,8 @@ def main():
     ap.add_argument("--num_samples", type=int, default=500)
     ap.add_argument("--class_id", type=int, default=8)
     ap.add_argument("--th_factor", type=float, default=0.65)
+    ap.add_argument("--feature_size", type=int, default=FEATURE_SIZE[0],
+                    help="side of the stored model outputs: 128 for the Xception copies, 64 for MobileNet (OS 8)")
     ap.add_argument("--out", default=os.path.join(ROOT, "data", "superres_root", "superres_output"))
     args = ap.parse_args()
 
@@ -41,7 +43,7 @@ def main():
                               decay_rate=HYPER["decay_rate"])
     sr = Superresolution(lambda_df=HYPER["lambda_df"], lambda_tv=HYPER["lambda_tv"], lambda_L2=HYPER["lambda_L2"],
                          lambda_L1=HYPER["lambda_L1"], num_iter=HYPER["num_iter"], num_aug=args.num_aug,
-                         optimizer=optimizer_obj, feature_size=FEATURE_SIZE)
+                         optimizer=optimizer_obj, feature_size=(args.feature_size, args.feature_size))
     paths = list_precomputed_data_paths(args.data, sort=False)[:args.num_samples]
     table = evaluate_precomputed(sr, paths, args.gt, args.standard, num_aug=args.num_aug, class_id=args.class_id,
                                  th_factor=args.th_factor, img_size=IMG_SIZE, out_dir=args.out, rank=rank, world=world)

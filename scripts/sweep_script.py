@@ -63,6 +63,8 @@ def main():
     ap.add_argument("--set", action="append", default=[], metavar="KEY=VALUE", help="override one hyper-parameter")
     ap.add_argument("--class_id", type=int, default=8)
     ap.add_argument("--th_factor", type=float, default=0.65)
+    ap.add_argument("--feature_size", type=int, default=FEATURE_SIZE[0],
+                    help="side of the stored model outputs: 128 for the Xception copies, 64 for MobileNet (OS 8)")
     ap.add_argument("--out", default=os.path.join(ROOT, "data", "superres_root", "superres_output"))
     args = ap.parse_args()
     config = load_config(args.config, args.set)
@@ -84,7 +86,7 @@ def main():
     sr = Superresolution(lambda_df=config["lambda_df"], lambda_tv=config["lambda_tv"], lambda_L2=config["lambda_L2"],
                          lambda_L1=config["lambda_L1"], num_iter=config["num_iter"], num_aug=config["num_aug"],
                          optimizer=optimizer_obj, use_BTV=config["use_BTV"], copy_dropout=config["copy_dropout"],
-                         feature_size=FEATURE_SIZE)
+                         feature_size=(args.feature_size, args.feature_size))
     path_list = list_precomputed_data_paths(args.data, sort=True)
     paths = path_list if config["num_samples"] is None else path_list[:config["num_samples"]]
     table = evaluate_precomputed(sr, paths, args.gt, args.standard, num_aug=config["num_aug"], class_id=args.class_id,

@@ -63,15 +63,18 @@ def main():
     ap.add_argument("--num-aug", type=int, default=NUM_AUG)
     ap.add_argument("--num-iter", type=int, default=NUM_ITER)
     ap.add_argument("--mode", default=MODE, choices=["argmax", "slice", "slice_max"])
+    ap.add_argument("--backbone", default=MODEL_BACKBONE, choices=["xception", "mobilenet"],
+                    help="mobilenet: model output 64x64 (OS 8), i.e. 8x super-resolution")
     args = ap.parse_args()
 
     model = DeeplabV3Plus(input_shape=IMG_SIZE + (3,), classes=21, OS=16, last_activation=None, load_weights=True,
-                          backbone=MODEL_BACKBONE, weights_path=args.weights).build_model(final_upsample=False)
+                          backbone=args.backbone, weights_path=args.weights).build_model(final_upsample=False)
     optimizer_obj = Optimizer(optimizer=OPTIMIZER, learning_rate=LEARNING_RATE, amsgrad=AMSGRAD,
                               lr_scheduler=LR_SCHEDULER, decay_steps=DECAY_STEPS, decay_rate=DECAY_RATE)
     superresolution_obj = Superresolution(lambda_df=LAMBDA_DF, lambda_tv=LAMBDA_TV, lambda_L2=LAMBDA_L2,
                                           lambda_L1=LAMBDA_L1, num_iter=args.num_iter, num_aug=args.num_aug,
-                                          optimizer=optimizer_obj, feature_size=FEATURE_SIZE)
+                                          optimizer=optimizer_obj,
+                                          feature_size=FEATURE_SIZE if args.backbone == "xception" else (IMG_SIZE[0] // 8, IMG_SIZE[1] // 8))
     class_masks, max_masks, angles, shifts, filename = compute_augmented_feature_maps(
         args.image, model, filter_class_id=CLASS_ID, mode=args.mode, num_aug=args.num_aug, angle_max=ANGLE_MAX,
         shift_max=SHIFT_MAX, image_size=IMG_SIZE, batch_size=BATCH_SIZE)

@@ -58,3 +58,21 @@ def test_single_image_demo(dev, tmp_path):
     assert "Aug. SR (argmax OPM) IoU" in out
     for t in ("aug", "max", "mean"):
         assert (tmp_path / "SR_output" / f"{t}_SR" / f"test_cat_{t}_SR.png").exists()
+
+
+def test_robustness_grid_script(dev, golden_dir, tmp_path):
+    """check_robustness.py on a 2 x 2 x 2 grid with the MobileNet backbone (the small model keeps the test short)."""
+    imgs = tmp_path / "JPEGImages"
+    gts = tmp_path / "gt"
+    imgs.mkdir()
+    gts.mkdir()
+    shutil.copy(os.path.join(golden_dir, "test_cat.jpg"), imgs / "7.jpg")
+    shutil.copy(os.path.join(golden_dir, "test_cat_gt.png"), gts / "7.png")
+    out = _run([os.path.join(ROOT, "scripts", "check_robustness.py"), "--images", str(imgs), "--gt", str(gts), "--backbone",
+                "mobilenet", "--image_size", "128", "--angles", "0.0", "0.3", "--shifts", "0", "20", "--out",
+                str(tmp_path / "rob")], str(tmp_path))
+    assert out.count("mIoU:") == 8 and "Done:" in out
+    import csv
+    rows = list(csv.reader(open(tmp_path / "rob" / "robustness_1_class_all_small.csv")))
+    assert rows[0] == ["Angle", "Shift_X", "Shift_Y", "mIoU"] and len(rows) == 9
+    assert all(0.0 <= float(r[3]) <= 1.0 for r in rows[1:])

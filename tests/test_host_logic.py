@@ -13,8 +13,7 @@ def test_deeplab_constructor_validation_matches_reference():
         DeeplabV3Plus(last_activation="relu")
     with pytest.raises(ValueError, match="Backbone"):
         DeeplabV3Plus(backbone="resnet")
-    with pytest.raises(NotImplementedError):
-        DeeplabV3Plus(backbone="mobilenet")
+    assert DeeplabV3Plus(backbone="mobilenet", OS=16).OS == 8         # model.py:53-55: mobilenet forces OS = 8
     with pytest.raises(NotImplementedError):
         DeeplabV3Plus(OS=8)
     m = DeeplabV3Plus(input_shape=(512, 512, 3), classes=21, OS=16, last_activation=None, load_weights=True,
@@ -23,6 +22,27 @@ def test_deeplab_constructor_validation_matches_reference():
         m.build_model(only_DCNN_output=True, only_ASPP_output=True)
     with pytest.raises(NotImplementedError):
         m.build_model(only_ASPP_output=True)
+
+
+def test_mobilenet_inventory_follows_the_reference_graph():
+    """model.py:308-379, 426-461: 16 inverted residual blocks (x6 expansion), strides (2, 1, 2, 1, 1, then 1 with dilation
+    2 / 4), 320 encoder channels, ASPP = image pooling + aspp0 only."""
+    from asr_amd import weights as W
+    blocks = W.mobilenet_blocks()
+    assert [b[2] for b in blocks] == [24, 24, 32, 32, 32, 64, 64, 64, 64, 96, 96, 96, 160, 160, 160, 320]
+    assert [b[3] for b in blocks] == [2, 1, 2] + [1] * 13 and [b[4] for b in blocks][-3:] == [4, 4, 4]
+    assert [b[5] for b in blocks] == [False, True, False, True, True, False, True, True, True, False, True, True, False,
+                                      True, True, False]
+    inv = W.layer_inventory(21, backbone="mobilenet")
+    names = [n for _k, n, _d in inv]
+    assert names[:6] == ["Conv", "Conv_BN", "expanded_conv_depthwise", "expanded_conv_depthwise_BN", "expanded_conv_project",
+                         "expanded_conv_project_BN"]
+    assert "expanded_conv_16_project_BN" in names and "aspp1_depthwise" not in names and "decoder_conv0_depthwise" not in names
+    convs = {n: d for k, n, d in inv if k == "conv"}
+    assert (convs["expanded_conv_1_expand"]["cin"], convs["expanded_conv_1_expand"]["cout"]) == (16, 96)
+    assert convs["concat_projection"]["cin"] == 512 and convs["aspp0"]["cin"] == 320
+    assert W.make_divisible(32 * 0.35, 8) == 16 and W.make_divisible(int(24 * 0.35), 8) == 8        # model.py:544-556
+    assert 2.0e6 < W.count_params(21, backbone="mobilenet") < 2.3e6
 
 
 def test_optimizer_schedule_and_persistent_counter():

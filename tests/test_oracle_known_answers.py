@@ -261,3 +261,17 @@ def test_copy_dropout_mask_is_drawn_once():
     m2 = sr.drop_mask(3)
     assert np.array_equal(m1, exp) and np.array_equal(m1, m2) and m1.sum() == 7
     assert np.array_equal(state, np.random.get_state()[1])       # no further draws
+
+
+def test_nearest_warp_and_mean_iou_known_answers():
+    """check_robustness.py:45-51 / utils.py:151-177: NEAREST reads I(round(y'), round(x')); Mean_IOU averages over the
+    labels present in the ground truth, void removed."""
+    x = torch.arange(30, dtype=torch.float32).reshape(1, 6, 5, 1)
+    y = tf_ops.translate(x, [[1, 2]], interpolation="nearest")[0, :, :, 0]
+    assert torch.equal(y[2:, 1:], x[0, :-2, :-1, 0]) and torch.all(y[:2] == 0) and torch.all(y[:, 0] == 0)
+    half = tf_ops.translate(x, [[0.5, 0.0]], interpolation="nearest")[0, :, :, 0]        # in_x = x - 0.5: std::round, half away
+    assert torch.equal(half[:, 1:], x[0, :, 1:, 0]) and torch.all(half[:, 0] == 0)       # 0.5 -> 1, 1.5 -> 2, -0.5 -> -1 (outside)
+    r = tf_ops.rotate(x, [0.4], interpolation="nearest")
+    assert set(np.unique(r.numpy())) <= set(np.unique(x.numpy())) | {0.0}               # labels are never blended
+    assert o_aug.Mean_IOU(np.array([0, 0, 8, 8, 255]), np.array([0, 8, 8, 8, 0])) == 0.5  # (1/3 + 2/3) / 2
+    assert np.isnan(o_aug.Mean_IOU(np.array([255, 255]), np.array([0, 0])))
