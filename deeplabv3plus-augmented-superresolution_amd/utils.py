@@ -58,6 +58,22 @@ def create_mask(pred_mask):
     return ops.argmax(t).cpu().numpy().astype(np.int64)[..., None]
 
 
+def get_prediction(model, input_image):
+    """utils.py:122-127: predict one image and argmax it."""
+    x = input_image if isinstance(input_image, torch.Tensor) else np.asarray(input_image, dtype=np.float32)
+    prediction = model.predict(x[None, ...] if not isinstance(x, torch.Tensor) else x[None].cpu().numpy())
+    return create_mask(prediction[0])
+
+
+def print_labels(masks):
+    """utils.py:144-148: label histograms of the (standard, super-resolved) mask pair."""
+    title = ["Standard Labels: ", "Superres Labels: "]
+    for i in range(2):
+        m = masks[i].cpu().numpy() if isinstance(masks[i], torch.Tensor) else np.asarray(masks[i])
+        values, count = np.unique(m, return_counts=True)
+        print(title[i] + str(dict(zip(values, count))))
+
+
 def _as_label_tensor(a, dev):
     if isinstance(a, torch.Tensor):
         return a.to(device=dev, dtype=torch.int32).contiguous().reshape(-1)

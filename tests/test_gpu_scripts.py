@@ -46,6 +46,10 @@ def test_two_stage_scripts(dev, golden_dir, tmp_path):
                 "--standard", str(std_dir), "--out", str(tmp_path / "sweep_out"), "--set", "optimizer=adagrad",
                 "--set", "learning_rate=0.01", "--set", "use_BTV=true", "--set", "copy_dropout=0.25", "--set", "num_aug=4",
                 "--set", "num_iter=12"], str(tmp_path))
+    out_th = _run([os.path.join(ROOT, "scripts", "threshold_tests.py"), "--data", str(data_dir), "--gt", str(gts),
+                   "--standard", str(std_dir), "--out", str(tmp_path / "th_out"), "--set", "num_aug=4", "--set", "num_iter=8",
+                   "--set", "learning_rate=0.001", "--set", "copy_dropout=0.25"], str(tmp_path))
+    assert "Best record:" in out_th and out_th.count("\n0.") >= 17 and (tmp_path / "th_out" / "th_1.csv").exists()
     rec = json.loads(out.strip().splitlines()[-1])
     assert set(rec) == {"aug_iou_single", "aug_iou_multiple", "standard_iou_single", "standard_iou_multiple", "mean_iou",
                         "max_iou", "config"}

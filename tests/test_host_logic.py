@@ -1,5 +1,7 @@
 """CPU tests of the host-side mirror: argument validation and error behaviour identical to the reference,
 float32 parameter math, plan bookkeeping -- nothing here touches a GPU."""
+import os
+
 import numpy as np
 import pytest
 
@@ -146,3 +148,33 @@ def test_weight_inventory_and_folding():
         W.load_weights("https://example.com/w.h5")
     with pytest.raises(ValueError):
         W.load_weights("/tmp/w.h5")
+
+
+def test_dataset_list_helpers(tmp_path):
+    """superres_utils.py:9-53, 81-90, 142-151: list files, integer-sorted ids, class filter by the sibling mask folder."""
+    from PIL import Image
+    from asr_amd.superresolution_scripts import superres_utils as su
+    jpg, seg = tmp_path / "JPEGImages", tmp_path / "SegmentationClassAug"
+    jpg.mkdir()
+    seg.mkdir()
+    for name, has in (("10", True), ("9", False), ("100", True)):
+        Image.fromarray(np.zeros((8, 8, 3), np.uint8)).save(jpg / f"{name}.jpg")
+        m = np.zeros((8, 8), np.uint8)
+        if has:
+            m[2:4, 2:4] = 8
+        Image.fromarray(m).save(seg / f"{name}.png")
+    lst = tmp_path / "list.txt"
+    lst.write_text("10\n9\n100\n")
+    paths = su.get_img_paths(str(lst), str(jpg), sort=True)
+    assert [os.path.basename(p) for p in paths] == ["9.jpg", "10.jpg", "100.jpg"]
+    assert su.get_img_paths(str(lst), str(seg), is_png=True, sort=False)[0].endswith("10.png")
+    assert su.class_in_image(paths[1], 8, image_size=(8, 8)) and not su.class_in_image(paths[0], 8, image_size=(8, 8))
+    assert [os.path.basename(p) for p in su.filter_images_by_class(paths, 8, num_images=1, image_size=(8, 8))] == ["10.jpg"]
+    n = su.normalize_coefficients({"lambda_tv": 0.84, "lambda_L2": 0.047, "lambda_L1": 0.0065})
+    assert abs(sum(n.values()) - 1.0) < 1e-12 and abs(n["lambda_tv"] - 0.84 / 0.8935) < 1e-12
+    root = tmp_path / "pre"
+    (root / "a").mkdir(parents=True)
+    (root / "b").mkdir()
+    for i in range(4):
+        (root / "a" / f"{i}.png").write_bytes(b"")
+    assert su.get_precomputed_folders_path(str(root), num_aug=2) == [str(root / "a")]
