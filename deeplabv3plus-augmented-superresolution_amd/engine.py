@@ -77,7 +77,7 @@ def _same_pad(in_size, k_eff, stride):
 class DeeplabEngine:
     """Folded / packed parameters on the device + per-(batch, H, W) launch plans."""
 
-    def __init__(self, weights: dict, classes=21, device=None, precision=None, backbone="xception", alpha=1.0):
+    def __init__(self, weights: dict, classes=21, device=None, precision=None, backbone="xception", alpha=1.0, OS=16):
         """precision: 'f32' = v_mfma_f32_32x32x2_f32 everywhere (exact f32 fmaf chains);
         'f16x3' = split-f16 MFMA (hi*hi + hi*lo + lo*hi, f32 accumulate; f32-grade results, ~2.4x faster)
         for the pointwise GEMMs with more than 64 output channels.  Default: $ASR_PRECISION or 'f16x3'."""
@@ -89,6 +89,12 @@ class DeeplabEngine:
             raise ValueError("Backbone must be either xception or mobilenet")
         self.backbone = backbone
         self.alpha = alpha
+        if backbone == "xception" and OS not in (8, 16):
+            raise ValueError("OS must be 8 or 16 for the Xception backbone")
+        # model.py:42-52: OS 8 trades the stride of entry block 3 for dilation in everything after it
+        self.OS = OS if backbone == "xception" else 8
+        self.entry_block3_stride, self.middle_block_rate, self.exit_block_rates, self.atrous_rates = \
+            ((1, 2, (2, 4), (12, 24, 36)) if self.OS == 8 else (2, 1, (1, 2), (6, 12, 18)))
         self.output_stride = 4 if backbone == "xception" else 8      # input size / logits size
         self.classes = classes
         self.logits_name = "logits_semantic" if "logits_semantic/kernel" in weights else "custom_logits_semantic"
@@ -307,13 +313,13 @@ class DeeplabEngine:
         release(a1)
         x = block(a2, "entry_flow_block1", "conv", 2, 1, False)
         x, skip = block(x, "entry_flow_block2", "conv", 2, 1, False, return_skip=True)
-        x = block(x, "entry_flow_block3", "conv", 2, 1, False)
+        x = block(x, "entry_flow_block3", "conv", self.entry_block3_stride, 1, False)
         # ---- middle flow (model.py:172-179) ----
         for i in range(16):
-            x = block(x, f"middle_flow_unit_{i + 1}", "sum", 1, 1, False)
+            x = block(x, f"middle_flow_unit_{i + 1}", "sum", 1, self.middle_block_rate, False)
         # ---- exit flow (model.py:181-190) ----
-        x = block(x, "exit_flow_block1", "conv", 1, 1, False)
-        x = block(x, "exit_flow_block2", None, 1, 2, True)
+        x = block(x, "exit_flow_block1", "conv", 1, self.exit_block_rates[0], False)
+        x = block(x, "exit_flow_block2", None, 1, self.exit_block_rates[1], True)
         # ---- ASPP (model.py:192-233) ----
         b, fh, fw, fc = x.shape
         cat = new((b, fh, fw, 1280))
@@ -326,7 +332,7 @@ class DeeplabEngine:
         release(pooled)
         release(pp)
         pw(x, "aspp0", out=cat, out_off=256, relu=True)
-        rates = (6, 12, 18)
+        rates = self.atrous_rates
         if fh * fw * 128 <= 160 * 1024 and not os.environ.get("ASR_NO_FUSED_ASPP"):
             # the three dilated depthwise convs read the same input: one fused launch stages each
             # 32-channel plane in LDS once (input read from HBM 1x instead of 3x)
@@ -336,7 +342,7 @@ class DeeplabEngine:
                 (x.ptr, p3["w"].data_ptr(), p3["b"].data_ptr(), ts[0].ptr, ts[1].ptr, ts[2].ptr, b, fh, fw, fc,
                  rates[0], rates[1], rates[2], x.ld, ts[0].ld, 0, 1),
                 "dw", 3 * 18.0 * b * fh * fw * fc, 3 * 4.0 * 2 * b * fh * fw * fc,
-                label=f"aspp_dw3 {fh}x{fw}x{fc} r6/12/18 fused", out=ts[0])
+                label=f"aspp_dw3 {fh}x{fw}x{fc} r{rates[0]}/{rates[1]}/{rates[2]} fused", out=ts[0])
             for i, t in enumerate(ts):
                 pw(t, f"aspp{i + 1}_pointwise", out=cat, out_off=512 + 256 * i, relu=True)
                 release(t)
@@ -369,7 +375,7 @@ class DeeplabEngine:
     def plan(self, B, H, Wd):
         key = (B, H, Wd)
         if key not in self._plans:
-            mult = 16 if self.backbone == "xception" else 8
+            mult = 16 if (self.backbone == "xception" and self.OS == 16) else 8
             if H % mult or Wd % mult:
                 raise ValueError(f"input size must be a multiple of {mult} for the {self.backbone} backbone (got {H}x{Wd})")
             self._plans[key] = self._build_plan(B, H, Wd)

@@ -1,10 +1,10 @@
 """``DeeplabV3Plus`` with the reference's constructor / ``build_model`` / ``predict`` surface
 (model.py:16-147), executing on hand-written gfx950 kernels through ``engine.DeeplabEngine``.
 
-Scope: Xception backbone at OS=16 and the MobileNetV2 backbone (always OS=8,
-model.py:53-55), ``classes`` logits, ``final_upsample`` on or off, ``last_activation`` None / softmax /
-sigmoid.  Xception at OS=8, the ``only_*`` decoders and ``reshape_outputs`` are validated like the reference
-and then rejected with NotImplementedError (not on the hot path).
+Scope: Xception backbone at OS=16 or OS=8 (model.py:42-52) and the MobileNetV2 backbone
+(always OS=8, model.py:53-55), ``classes`` logits, ``final_upsample`` on or off, ``last_activation`` None /
+softmax / sigmoid.  The ``only_*`` decoders and ``reshape_outputs`` are validated like the reference and then
+rejected with NotImplementedError (not on the hot path).
 """
 from __future__ import annotations
 
@@ -28,8 +28,8 @@ class DeeplabV3Plus:
             raise ValueError("The last_activation parameter must be either None, softmax or sigmoid")
         if not (backbone in {"xception", "mobilenet"}):
             raise ValueError("Backbone must be either xception or mobilenet")
-        if backbone == "xception" and OS != 16:
-            raise NotImplementedError("only OS=16 is on the accelerated path for Xception (model.py:48-52)")
+        if backbone == "xception" and OS not in (8, 16):
+            raise ValueError("OS must be 8 or 16 (model.py:42-52 only distinguishes OS == 8)")
         if backbone == "mobilenet":
             OS = 8                                     # model.py:53-55: OS is set to 8 for the mobilenet backbone
         if reshape_outputs:
@@ -60,7 +60,7 @@ class DeeplabV3Plus:
             # The pretrained .h5 is a network download (model.py:134-143): unavailable offline.
             params = W.make_synthetic_weights(self.synthetic_seed, self.classes, backbone=self.backbone, alpha=self.alpha)
         return DeeplabModel(params, self.input_shape, self.classes, final_upsample, self.last_activation,
-                            precision=self.precision, backbone=self.backbone, alpha=self.alpha)
+                            precision=self.precision, backbone=self.backbone, alpha=self.alpha, OS=self.OS)
 
 
 class DeeplabModel:
@@ -68,14 +68,14 @@ class DeeplabModel:
     (augmentation_utils.py:76)."""
 
     def __init__(self, params, input_shape, classes, final_upsample, last_activation, precision=None,
-                 backbone="xception", alpha=1.0):
+                 backbone="xception", alpha=1.0, OS=16):
         self.input_shape = tuple(input_shape)
         self.classes = classes
         self.final_upsample = final_upsample
         self.last_activation = last_activation
         self.backbone = backbone
-        self.name = f"DLV3Plus-{backbone}-OS{16 if backbone == 'xception' else 8}"      # model.py:71
-        self.engine = DeeplabEngine(params, classes, precision=precision, backbone=backbone, alpha=alpha)
+        self.name = f"DLV3Plus-{backbone}-OS{OS if backbone == 'xception' else 8}"      # model.py:71
+        self.engine = DeeplabEngine(params, classes, precision=precision, backbone=backbone, alpha=alpha, OS=OS)
         self.precision = self.engine.precision
         self.device = self.engine.device
 

@@ -33,11 +33,14 @@ class OracleDeeplabV3Plus:
     """Xception backbone, OS=16 only (model.py:48-52: entry_block3_stride 2, middle rate 1,
     exit rates (1,2), atrous rates (6,12,18))."""
 
-    def __init__(self, weights: dict, classes=21, last_activation=None, backbone="xception"):
+    def __init__(self, weights: dict, classes=21, last_activation=None, backbone="xception", OS=16):
         self.w = {k: torch.as_tensor(np.asarray(v, dtype=np.float32)) for k, v in weights.items()}
         self.classes = classes
         self.last_activation = last_activation
         self.backbone = backbone
+        # model.py:42-52
+        self.entry_block3_stride, self.middle_block_rate, self.exit_block_rates, self.atrous_rates = \
+            ((1, 2, (2, 4), (12, 24, 36)) if OS == 8 else (2, 1, (1, 2), (6, 12, 18)))
 
     # ---- Keras layers (NCHW inside) ---------------------------------------------------
     def conv(self, x, name, stride=1, padding="same", rate=1):
@@ -175,15 +178,15 @@ class OracleDeeplabV3Plus:
         x = self.xception_block(x, "entry_flow_block1", "conv", 2)
         stages["block1"] = x
         x, skip = self.xception_block(x, "entry_flow_block2", "conv", 2, return_skip=True)
-        x = self.xception_block(x, "entry_flow_block3", "conv", 2)
+        x = self.xception_block(x, "entry_flow_block3", "conv", self.entry_block3_stride)
         stages["entry"] = x
         # middle flow (model.py:172-179)
         for i in range(16):
-            x = self.xception_block(x, f"middle_flow_unit_{i + 1}", "sum", 1, rate=1)
+            x = self.xception_block(x, f"middle_flow_unit_{i + 1}", "sum", 1, rate=self.middle_block_rate)
         stages["middle"] = x
         # exit flow (model.py:181-190)
-        x = self.xception_block(x, "exit_flow_block1", "conv", 1, rate=1)
-        x = self.xception_block(x, "exit_flow_block2", None, 1, rate=2, depth_activation=True)
+        x = self.xception_block(x, "exit_flow_block1", "conv", 1, rate=self.exit_block_rates[0])
+        x = self.xception_block(x, "exit_flow_block2", None, 1, rate=self.exit_block_rates[1], depth_activation=True)
         stages["exit"] = x
         # ASPP (model.py:192-233)
         fh, fw = x.shape[2:]
@@ -191,9 +194,9 @@ class OracleDeeplabV3Plus:
         pool = F.relu(self.bn(self.conv(pool, "image_pooling"), "image_pooling_BN", 1e-5))
         pool = self.resize(pool, (fh, fw))
         b0 = F.relu(self.bn(self.conv(x, "aspp0"), "aspp0_BN", 1e-5))
-        b1 = self.sepconv_bn(x, "aspp1", rate=6, depth_activation=True)
-        b2 = self.sepconv_bn(x, "aspp2", rate=12, depth_activation=True)
-        b3 = self.sepconv_bn(x, "aspp3", rate=18, depth_activation=True)
+        b1 = self.sepconv_bn(x, "aspp1", rate=self.atrous_rates[0], depth_activation=True)
+        b2 = self.sepconv_bn(x, "aspp2", rate=self.atrous_rates[1], depth_activation=True)
+        b3 = self.sepconv_bn(x, "aspp3", rate=self.atrous_rates[2], depth_activation=True)
         x = torch.cat([pool, b0, b1, b2, b3], dim=1)
         x = F.relu(self.bn(self.conv(x, "concat_projection"), "concat_projection_BN", 1e-5))
         stages["aspp"] = x

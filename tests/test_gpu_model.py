@@ -38,6 +38,21 @@ def test_engine_logits_match_oracle(dev, synthetic, precision):
     assert agree >= 0.999, agree
 
 
+def test_xception_os8_matches_oracle(dev, synthetic):
+    """model.py:42-47: OS = 8 -- entry block 3 at stride 1, middle flow dilated by 2, exit flow by (2, 4), ASPP rates
+    (12, 24, 36); same weights, same decoder."""
+    from asr_amd.model import DeeplabModel
+    rng = np.random.default_rng(23)
+    x = rng.random((2, 64, 64, 3), dtype=np.float32)
+    ref, st = OracleDeeplabV3Plus(synthetic, OS=8).forward(x, return_stages=True)
+    assert st["exit"].shape == (2, 8, 8, 2048)                       # 64 / 8
+    model = DeeplabModel(synthetic, (64, 64, 3), 21, final_upsample=False, last_activation=None, OS=8)
+    assert model.name == "DLV3Plus-xception-OS8"
+    got = model.predict(x, batch_size=2)
+    assert got.shape == ref.shape == (2, 16, 16, 21)
+    np.testing.assert_allclose(got, ref, rtol=0, atol=2e-4 * np.abs(ref).max())
+
+
 def test_final_upsample_matches_oracle(dev, synthetic):
     from asr_amd.model import DeeplabModel
     rng = np.random.default_rng(22)

@@ -16,8 +16,9 @@ def test_deeplab_constructor_validation_matches_reference():
     with pytest.raises(ValueError, match="Backbone"):
         DeeplabV3Plus(backbone="resnet")
     assert DeeplabV3Plus(backbone="mobilenet", OS=16).OS == 8         # model.py:53-55: mobilenet forces OS = 8
-    with pytest.raises(NotImplementedError):
-        DeeplabV3Plus(OS=8)
+    assert DeeplabV3Plus(OS=8).OS == 8
+    with pytest.raises(ValueError, match="OS"):
+        DeeplabV3Plus(OS=32)
     m = DeeplabV3Plus(input_shape=(512, 512, 3), classes=21, OS=16, last_activation=None, load_weights=True,
                       backbone="xception")
     with pytest.raises(ValueError, match="only_DCNN_output"):
