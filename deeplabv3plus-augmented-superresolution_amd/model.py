@@ -3,8 +3,8 @@
 
 Scope: Xception backbone at OS=16 or OS=8 (model.py:42-52) and the MobileNetV2 backbone
 (always OS=8, model.py:53-55), ``classes`` logits, ``final_upsample`` on or off, ``last_activation`` None /
-softmax / sigmoid.  The ``only_*`` decoders and ``reshape_outputs`` are validated like the reference and then
-rejected with NotImplementedError (not on the hot path).
+softmax / sigmoid, ``reshape_outputs``.  The ``only_*`` decoders and ``final_class_prediction=False`` are validated
+like the reference and then rejected with NotImplementedError (not on the hot path).
 """
 from __future__ import annotations
 
@@ -32,8 +32,6 @@ class DeeplabV3Plus:
             raise ValueError("OS must be 8 or 16 (model.py:42-52 only distinguishes OS == 8)")
         if backbone == "mobilenet":
             OS = 8                                     # model.py:53-55: OS is set to 8 for the mobilenet backbone
-        if reshape_outputs:
-            raise NotImplementedError("reshape_outputs is not on the accelerated path")
         if input_tensor is not None:
             raise NotImplementedError("input_tensor (Keras graph splicing) has no meaning here")
         self.weights = weights
@@ -41,6 +39,7 @@ class DeeplabV3Plus:
         self.classes = classes
         self.last_activation = last_activation
         self.load_weights = load_weights
+        self.reshape_outputs = reshape_outputs
         self.backbone = backbone
         self.alpha = alpha
         self.OS = OS
@@ -60,7 +59,8 @@ class DeeplabV3Plus:
             # The pretrained .h5 is a network download (model.py:134-143): unavailable offline.
             params = W.make_synthetic_weights(self.synthetic_seed, self.classes, backbone=self.backbone, alpha=self.alpha)
         return DeeplabModel(params, self.input_shape, self.classes, final_upsample, self.last_activation,
-                            precision=self.precision, backbone=self.backbone, alpha=self.alpha, OS=self.OS)
+                            precision=self.precision, backbone=self.backbone, alpha=self.alpha, OS=self.OS,
+                            reshape_outputs=self.reshape_outputs)
 
 
 class DeeplabModel:
@@ -68,8 +68,9 @@ class DeeplabModel:
     (augmentation_utils.py:76)."""
 
     def __init__(self, params, input_shape, classes, final_upsample, last_activation, precision=None,
-                 backbone="xception", alpha=1.0, OS=16):
+                 backbone="xception", alpha=1.0, OS=16, reshape_outputs=False):
         self.input_shape = tuple(input_shape)
+        self.reshape_outputs = reshape_outputs
         self.classes = classes
         self.final_upsample = final_upsample
         self.last_activation = last_activation
@@ -96,6 +97,11 @@ class DeeplabModel:
                 logits = logits.clone()
             outs.append(logits)
         out = outs[0] if len(outs) == 1 else torch.cat(outs, dim=0)
+        if self.reshape_outputs:
+            # model.py:120-122: Reshape((input_h * input_w, classes)) -- only meaningful with final_upsample, like the reference
+            if out.shape[1] * out.shape[2] != self.input_shape[0] * self.input_shape[1]:
+                raise ValueError("reshape_outputs needs the model output at the input size (final_upsample=True)")
+            out = out.reshape(out.shape[0], self.input_shape[0] * self.input_shape[1], self.classes)
         if self.last_activation in ("softmax", "sigmoid"):
             out = ops.class_activation(out.contiguous(), self.last_activation)
         return out

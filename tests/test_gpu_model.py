@@ -60,6 +60,11 @@ def test_final_upsample_matches_oracle(dev, synthetic):
     ref = OracleDeeplabV3Plus(synthetic).forward(x, final_upsample=True)
     got = DeeplabModel(synthetic, (64, 64, 3), 21, True, None).predict(x)
     np.testing.assert_allclose(got, ref, rtol=0, atol=2e-4 * np.abs(ref).max())
+    # reshape_outputs (model.py:120-122) + softmax over the class axis of the flattened output
+    flat = DeeplabModel(synthetic, (64, 64, 3), 21, True, "softmax", reshape_outputs=True).predict(x)
+    ref_sm = OracleDeeplabV3Plus(synthetic, last_activation="softmax").forward(x, final_upsample=True)
+    assert flat.shape == (1, 64 * 64, 21)
+    np.testing.assert_allclose(flat, ref_sm.reshape(1, 64 * 64, 21), rtol=0, atol=2e-5)
 
 
 def test_hot_path_config1_test_cat(dev, synthetic, golden_dir, tmp_path):
