@@ -181,7 +181,14 @@ __global__ __launch_bounds__(256) void dw_stream_kernel(DwArgs p, int tiles_x) {
 // of an outstanding load is ever copied).  s_waitcnt vmcnt(N) then waits for exactly the row that enters the window
 // and leaves the younger loads and the previous stores in flight; with a branch or a copy in the way the wait
 // degenerates to vmcnt(0) and every "prefetch" is synchronous.
-template <int R, int S, int SROWS, int PF>
+// SPLIT: the output is written in the split-f16 A-operand format of pw_gemm_f16x3_pre_kernel instead of f32 -- per pixel
+// and per chunk of 32 channels one 128-byte line [hi(32 halfs) | lo(32 halfs)], hi = f16(v), lo = f16(v - hi): exactly
+// the split the pointwise GEMM would apply to the f32 value on its way into LDS (same bytes per element, bit-identical
+// GEMM result), which lets that GEMM take its A tiles by LDS-DMA without staging registers or conversion work.  ldy is
+// then the number of chunks per pixel; channels c .. 32 * ldy - 1 are written as zeros (the GEMM reads whole chunks).
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+template <int R, int S, int SROWS, int PF, bool SPLIT>
 __global__ __launch_bounds__(256) void dw_stream_full_kernel(DwArgs p, int tiles_x) {
     constexpr int WIN = 2 * R + 1;
     static_assert(SROWS % PF == 0, "strip length must be a multiple of the prefetch depth");
@@ -192,6 +199,20 @@ __global__ __launch_bounds__(256) void dw_stream_full_kernel(DwArgs p, int tiles
     const int ox = tx * SCOLS + col;
     const int oy0 = blockIdx.y * SROWS;
     const int b = blockIdx.z;
+    _Float16* ysplit = nullptr;
+    long long split_row_stride = 0;
+    if (SPLIT) {
+        ysplit = reinterpret_cast<_Float16*>(p.y) + (((long long)b * p.h_out * p.w_out + ox) * p.ldy + (ch >> 5)) * 64 + (ch & 31);
+        split_row_stride = (long long)p.w_out * p.ldy * 64;
+        if (ox < p.w_out && ch >= p.c && ch < p.ldy * 32) {      // padding channels of the last chunk: zeros, no loads
+            const f16x4 z = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+            for (int r = 0; r < SROWS; ++r) {
+                _Float16* o = ysplit + (long long)(oy0 + r) * split_row_stride;
+                *reinterpret_cast<f16x4*>(o) = z;
+                *reinterpret_cast<f16x4*>(o + 32) = z;
+            }
+        }
+    }
     if (ch >= p.c || ox >= p.w_out) return;
     const float* xin = p.x + (long long)b * p.h_in * p.w_in * p.ldx + ch;
     float* yout = p.y + ((long long)b * p.h_out * p.w_out + ox) * p.ldy + ch;
@@ -247,7 +268,32 @@ __global__ __launch_bounds__(256) void dw_stream_full_kernel(DwArgs p, int tiles
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx) acc += win[ky * R][kx] * wk[ky * 3 + kx];
             acc = post_act4(acc, p.post_relu);
-            *reinterpret_cast<f32x4*>(yout + (long long)(oy0 + r) * p.w_out * p.ldy) = acc;
+            if (SPLIT) {
+                f16x4 hi, lo;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const _Float16 h = (_Float16)acc[e];
+                    hi[e] = h;
+                    lo[e] = (_Float16)(acc[e] - (float)h);
+                }
+                // Lane pairs (channel quads 2j, 2j+1; c % 8 == 0) trade halves through DPP so that each lane issues ONE
+                // 16-byte store -- the even lane the 8 hi halfs of both quads, the odd lane their 8 lo halfs -- instead of
+                // two 8-byte stores per lane (which cost the split variant 15 % of the kernel's bandwidth).
+                typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+                typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+                const u32x2 h2 = __builtin_bit_cast(u32x2, hi), l2 = __builtin_bit_cast(u32x2, lo);
+                const bool even = (c4 & 1) == 0;
+                const u32x2 give = even ? l2 : h2;
+                u32x2 got;
+                got.x = __shfl_xor(give.x, 1, 64);
+                got.y = __shfl_xor(give.y, 1, 64);
+                const u32x4 out = even ? u32x4{h2.x, h2.y, got.x, got.y} : u32x4{got.x, got.y, l2.x, l2.y};
+                // even lane: hi of channels ch .. ch+7 at its own hi slot; odd lane: lo of channels ch-4 .. ch+3 at the lo slot
+                _Float16* o = ysplit + (long long)(oy0 + r) * split_row_stride + (even ? 0 : 32 - 4);
+                *reinterpret_cast<u32x4*>(o) = out;
+            } else {
+                *reinterpret_cast<f32x4*>(yout + (long long)(oy0 + r) * p.w_out * p.ldy) = acc;
+            }
         }
     }
 }
@@ -437,7 +483,7 @@ __global__ __launch_bounds__(256) void dw_direct_kernel(DwArgs p) {
 }
 
 template <int R, int S>
-void launch_stream(const DwArgs& p, hipStream_t s) {
+int launch_stream(const DwArgs& p, hipStream_t s, bool split = false) {
     static const int srows_env = getenv("ASR_DW_SROWS") ? atoi(getenv("ASR_DW_SROWS")) : 0;
     static const int pf_env = getenv("ASR_DW_PF") ? atoi(getenv("ASR_DW_PF")) : 0;
     const int tiles_x = (int)asr_cdiv(p.w_out, SCOLS), chunks = (int)asr_cdiv(p.c, 64);
@@ -447,15 +493,21 @@ void launch_stream(const DwArgs& p, hipStream_t s) {
     // per image), 1 on the large ones (measured).  ASR_DW_PF = 1 | 2 | 4 overrides, -1 = generic kernel.
     const int pf = pf_env ? pf_env : (p.h_out <= 32 ? 4 : 1);
     if (pf > 0 && p.h_out % srows == 0 && (srows == 16 || srows == 32)) {
-#define ASR_DW_FULL(SR_, PF_) hipLaunchKernelGGL((dw_stream_full_kernel<R, S, SR_, PF_>), grid, dim3(256), 0, s, p, tiles_x)
+#define ASR_DW_FULL(SR_, PF_)                                                                                              \
+    do {                                                                                                                   \
+        if (split) hipLaunchKernelGGL((dw_stream_full_kernel<R, S, SR_, PF_, true>), grid, dim3(256), 0, s, p, tiles_x);    \
+        else hipLaunchKernelGGL((dw_stream_full_kernel<R, S, SR_, PF_, false>), grid, dim3(256), 0, s, p, tiles_x);         \
+    } while (0)
         if (srows == 16) { if (pf == 1) ASR_DW_FULL(16, 1); else if (pf == 2) ASR_DW_FULL(16, 2); else ASR_DW_FULL(16, 4); }
         else { if (pf == 1) ASR_DW_FULL(32, 1); else if (pf == 2) ASR_DW_FULL(32, 2); else ASR_DW_FULL(32, 4); }
 #undef ASR_DW_FULL
-        return;
+        return ASR_OK;
     }
+    ASR_UNSUPPORTED(split, "asr_dwconv3x3_nhwc_split_f16: needs h_out to be a multiple of the strip height (%d)", srows);
     if (srows == 8) hipLaunchKernelGGL((dw_stream_kernel<R, S, 8>), grid, dim3(256), 0, s, p, tiles_x);
     else if (srows == 16) hipLaunchKernelGGL((dw_stream_kernel<R, S, 16>), grid, dim3(256), 0, s, p, tiles_x);
     else hipLaunchKernelGGL((dw_stream_kernel<R, S, 32>), grid, dim3(256), 0, s, p, tiles_x);
+    return ASR_OK;
 }
 
 }  // namespace
@@ -506,6 +558,38 @@ extern "C" int asr_dwconv3x3_nhwc_f32(const float* x, const float* w, const floa
         const long long g = asr_cdiv(total, 256);
         hipLaunchKernelGGL(dw_direct_kernel, dim3((unsigned)(g < 8192 ? g : 8192)), dim3(256), 0, s, p);
     }
+    ASR_LAUNCH_CHECK();
+    return ASR_OK;
+}
+
+// Depthwise 3x3 whose output feeds asr_pwconv_mfma_f16x3_presplit: y is written as split-f16 chunks (see
+// dw_stream_full_kernel), ldy_chunks = ceil(c / 32) chunks of 128 bytes per pixel.
+extern "C" int asr_dwconv3x3_nhwc_split_f16(const float* x, const float* w, const float* bias, void* y_split, int batch, int h_in,
+                                            int w_in, int c, int stride, int rate, int pad_top, int pad_left, int h_out,
+                                            int w_out, int ldx, int ldy_chunks, int pre_relu, int post_relu,
+                                            asr_stream_t stream) {
+    ASR_REQUIRE(x && w && bias && y_split, "asr_dwconv3x3_nhwc_split_f16: null pointer");
+    ASR_REQUIRE(batch > 0 && batch <= 65535 && h_in > 0 && w_in > 0 && c > 0 && h_out > 0 && w_out > 0 && stride > 0 && rate > 0 &&
+                    pad_top >= 0 && pad_left >= 0,
+                "asr_dwconv3x3_nhwc_split_f16: bad geometry");
+    ASR_REQUIRE(ldx >= c && ldy_chunks * 32 >= c, "asr_dwconv3x3_nhwc_split_f16: ldx < c or ldy_chunks * 32 < c");
+    ASR_REQUIRE((long long)(h_out - 1) * stride - pad_top <= h_in - 1 && (long long)(w_out - 1) * stride - pad_left <= w_in - 1,
+                "asr_dwconv3x3_nhwc_split_f16: output %dx%d does not fit input %dx%d (stride %d)", h_out, w_out, h_in, w_in, stride);
+    ASR_UNSUPPORTED((c & 7) || (ldx & 3), "asr_dwconv3x3_nhwc_split_f16: c must be a multiple of 8 and ldx of 4");
+    ASR_UNSUPPORTED(ldy_chunks * 32 > ((c + 63) / 64) * 64, "asr_dwconv3x3_nhwc_split_f16: ldy_chunks beyond ceil64(c) / 32");
+    ASR_UNSUPPORTED((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(bias)) & 15 ||
+                        (reinterpret_cast<uintptr_t>(y_split) & 127),
+                    "asr_dwconv3x3_nhwc_split_f16: x, w, bias must be 16-byte and y_split 128-byte aligned");
+    ASR_UNSUPPORTED(!((stride == 1 && (rate == 1 || rate == 2)) || (stride == 2 && rate == 1)),
+                    "asr_dwconv3x3_nhwc_split_f16: needs (stride 1, rate 1|2) or (stride 2, rate 1)");
+    DwArgs p{x, w, bias, reinterpret_cast<float*>(y_split), batch, h_in, w_in, c, h_out, w_out, stride, rate, pad_top, pad_left,
+             pre_relu, post_relu, ldx, ldy_chunks};
+    hipStream_t s = asr_stream(stream);
+    int rc;
+    if (stride == 1 && rate == 1) rc = launch_stream<1, 1>(p, s, true);
+    else if (stride == 1) rc = launch_stream<2, 1>(p, s, true);
+    else rc = launch_stream<1, 2>(p, s, true);
+    if (rc != ASR_OK) return rc;
     ASR_LAUNCH_CHECK();
     return ASR_OK;
 }

@@ -54,7 +54,7 @@ struct PwArgs {
 // (32 x TN*32) half-tile through its own slice of the (now idle) staging LDS and stores whole
 // 16-byte pieces: 16 lanes cover one 256-byte row segment, 4x fewer store instructions.
 // The caller guarantees (barrier) that no wave still reads the staging tiles.
-template <int WM, int WN, int TM, int TN>
+template <int WM, int WN, int TM, int TN, bool RES_AHEAD = false>
 __device__ __forceinline__ void pw_epilogue(const PwArgs& p, f32x16 (&acc)[TM][TN], float* smem, int tile_m, int tile_n,
                                             int wave, int lane) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
@@ -67,12 +67,28 @@ __device__ __forceinline__ void pw_epilogue(const PwArgs& p, f32x16 (&acc)[TM][T
     const bool vec_ok = ((p.N & 3) == 0) && ((p.ldy & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.y) & 15) == 0) &&
                         (!p.res || (((p.ldres & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.res) & 15) == 0)));
     const int n_wave = tile_n * BN + wn * WCOLS;
+    const int c4 = lane % LPR, r_in = lane / LPR;
+    const int n = n_wave + c4 * 4;
+    const bool res_vec = vec_ok && p.res != nullptr;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
+        const long long m_base = (long long)tile_m * BM + (wm * TM + i) * 32;
+        // RES_AHEAD (kernels with registers to spare: the 256 x 256 LDS-DMA kernel): the residual pieces of this
+        // 32-row slab are requested before the accumulators go through the LDS (clamped addresses, no branch around the
+        // loads), so they arrive during the transposition instead of one waited-for round trip per piece in the store loop.
+        f32x4 rv[RES_AHEAD ? 32 / RPI : 1];
+        if (RES_AHEAD && res_vec) {
+            const float* rbase = p.res + (n < p.N ? n : 0);
+#pragma unroll
+            for (int q = 0; q < 32 / RPI; ++q) {
+                const long long m = m_base + q * RPI + r_in;
+                rv[q] = *reinterpret_cast<const f32x4*>(rbase + (m < p.M ? m : p.M - 1) * p.ldres);
+            }
+        }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const int n = n_wave + j * 32 + l32;
-            const float bv = (p.bias && n < p.N) ? p.bias[n] : 0.f;
+            const int nj = n_wave + j * 32 + l32;
+            const float bv = (p.bias && nj < p.N) ? p.bias[nj] : 0.f;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 float v = acc[i][j][e] + bv;
@@ -81,25 +97,25 @@ __device__ __forceinline__ void pw_epilogue(const PwArgs& p, f32x16 (&acc)[TM][T
                 stage[((e & 3) + 8 * (e >> 2) + 4 * hh) * WCOLS + j * 32 + l32] = v;
             }
         }
-        const long long m_base = (long long)tile_m * BM + (wm * TM + i) * 32;
-        const int c4 = lane % LPR, r_in = lane / LPR;
-        const int n = n_wave + c4 * 4;
 #pragma unroll
-        for (int rr = 0; rr < 32; rr += RPI) {
-            const int r = rr + r_in;
+        for (int q = 0; q < 32 / RPI; ++q) {
+            const int r = q * RPI + r_in;
             const long long m = m_base + r;
             f32x4 v = *reinterpret_cast<const f32x4*>(stage + r * WCOLS + c4 * 4);
             if (m < p.M && n < p.N) {
                 if (vec_ok) {
-                    if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + m * p.ldres + n);
+                    if (p.res) {
+                        if (RES_AHEAD) v += rv[q];
+                        else v += *reinterpret_cast<const f32x4*>(p.res + m * p.ldres + n);
+                    }
                     *reinterpret_cast<f32x4*>(p.y + m * p.ldy + n) = v;
                 } else {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        if (n + q < p.N) {
-                            float o = v[q];
-                            if (p.res) o += p.res[m * p.ldres + n + q];
-                            p.y[m * p.ldy + n + q] = o;
+                    for (int t = 0; t < 4; ++t)
+                        if (n + t < p.N) {
+                            float o = v[t];
+                            if (p.res) o += p.res[m * p.ldres + n + t];
+                            p.y[m * p.ldy + n + t] = o;
                         }
                 }
             }
@@ -511,6 +527,114 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void pw_gemm_f16x3_kernel(PwArg
 #endif
 }
 
+// =================================================================================================
+// Pre-split A operand (asr_pwconv_mfma_f16x3_presplit): the producer of the activations -- the depthwise kernel of a
+// separable conv, asr_dwconv3x3_nhwc_split_f16 -- already wrote them as split-f16 chunks, per row and 32-deep K chunk
+// one 128-byte line [hi(32) | lo(32)].  Both operands then reach LDS by LDS-DMA (global_load_lds_dwordx4): no staging
+// registers, no conversion VALU, no ds_write, which is what lets a 256 x 256 tile (half the staged bytes per flop of
+// 128 x 128: the CU takes in only ~20-30 B/clk from L2 under load, DESIGN.md "GEMM phase profile") run with two LDS
+// stages at 2 waves per SIMD.  8 waves, each 64 x 128 of the tile; BK = 32; same MFMA sequence per accumulator as the
+// in-kernel-split kernel, so the results are bit-identical to it.
+//   LDS stage (64 KB): A [256 rows][8 slots of 16 B: hi oct 0-3, lo oct 0-3], slot XOR-swizzled by (row >> 1) & 7 --
+//   applied on the per-lane SOURCE address, the DMA destination is lane-linear --, then B_hi, B_lo [4 oct][256 col][8].
+// =================================================================================================
+typedef __attribute__((address_space(3))) void* asr_lds_ptr;
+typedef const __attribute__((address_space(1))) void* asr_gbl_ptr;
+
+__device__ __forceinline__ void glds16(const void* g, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((asr_gbl_ptr)g, (asr_lds_ptr)lds_wave_base, 16, 0, 0);
+}
+
+template <int WM, int WN, int TM, int TN>
+__global__ __launch_bounds__(WM * WN * 64, 2) void pw_gemm_f16x3_pre_kernel(PwArgs p) {
+    constexpr int NT = WM * WN * 64, BM = WM * TM * 32, BN = WN * TN * 32;
+    constexpr int A_BYTES = BM * 128, B_BYTES = 4 * BN * 16, STAGE_BYTES = A_BYTES + 2 * B_BYTES;
+    constexpr int PA = BM * 8 / NT, PB = 4 * BN / NT;          // 16-byte DMA pieces per thread: A, B (per plane)
+    static_assert((BM * 8) % NT == 0 && (4 * BN) % NT == 0, "tile / thread-count mismatch");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    char* const lds = reinterpret_cast<char*>(smem);
+
+    const int nwg = gridDim.x, orig = blockIdx.x;
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
+    const int lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+    const int tile_m = lid / p.tiles_n, tile_n = lid % p.tiles_n;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int l32 = lane & 31, hh = lane >> 5;
+
+    // per-thread DMA sources: A piece q = tid + NT * i -> (row q >> 3, LDS slot q & 7, holding global slot ^ swizzle)
+    const char* a_src[PA];
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+        const int q = tid + NT * i, row = q >> 3, slot = (q & 7) ^ ((row >> 1) & 7);
+        long long m = (long long)tile_m * BM + row;
+        if (m >= p.M) m = p.M - 1;                             // rows past the end re-read the last row; never stored
+        a_src[i] = reinterpret_cast<const char*>(p.x) + (m * p.ldx) * 128 + slot * 16;   // + kt * 128 per K chunk
+    }
+    const long long plane_bytes = (long long)p.Kpad * p.Npad * 2;
+    const char* b_src[PB];
+#pragma unroll
+    for (int i = 0; i < PB; ++i) {
+        const int q = tid + NT * i, oct = q / BN, col = q % BN;
+        b_src[i] = reinterpret_cast<const char*>(p.wp) + (((long long)oct * p.Npad) + (long long)tile_n * BN + col) * 16;  // + kt * 4 * Npad * 16
+    }
+    const long long b_kstep = (long long)4 * p.Npad * 16;
+
+    auto issue_tile = [&](int kt, int stage) {
+        char* const st = lds + stage * STAGE_BYTES;
+#pragma unroll
+        for (int i = 0; i < PA; ++i) glds16(a_src[i] + (long long)kt * 128, st + (wave * 64 + NT * i) * 16);
+#pragma unroll
+        for (int i = 0; i < PB; ++i) {
+            glds16(b_src[i] + kt * b_kstep, st + A_BYTES + (wave * 64 + NT * i) * 16);
+            glds16(b_src[i] + kt * b_kstep + plane_bytes, st + A_BYTES + B_BYTES + (wave * 64 + NT * i) * 16);
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int KT = p.Kpad / BK;
+    issue_tile(0, 0);
+    __syncthreads();                                           // drains the DMA (vmcnt(0)) and publishes stage 0
+    for (int kt = 0; kt < KT; ++kt) {
+        const char* const st = lds + (kt & 1) * STAGE_BYTES;
+        // All 8 DMA pieces of the next tile go out before the MFMAs (spreading them between the MFMA groups, or letting
+        // half of the waves request theirs after their MFMAs, measured equal / 8 % slower).
+        if (kt + 1 < KT) issue_tile(kt + 1, (kt + 1) & 1);     // the other stage: last read before the previous barrier
+#pragma unroll
+        for (int s = 0; s < BK / 16; ++s) {
+            const int oct = 2 * s + hh;
+            f16x8 ah[TM], al[TM];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int row = (wm * TM + i) * 32 + l32, swz = (row >> 1) & 7;
+                ah[i] = *reinterpret_cast<const f16x8*>(st + row * 128 + ((oct ^ swz) << 4));
+                al[i] = *reinterpret_cast<const f16x8*>(st + row * 128 + (((4 + oct) ^ swz) << 4));
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int col = (wn * TN + j) * 32 + l32;
+                const f16x8 bh = *reinterpret_cast<const f16x8*>(st + A_BYTES + (oct * BN + col) * 16);
+                const f16x8 bl = *reinterpret_cast<const f16x8*>(st + A_BYTES + B_BYTES + (oct * BN + col) * 16);
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh, acc[i][j], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();                                       // next stage landed (vmcnt(0)) and everyone is done reading this one
+    }
+    pw_epilogue<WM, WN, TM, TN, true>(p, acc, smem, tile_m, tile_n, wave, lane);
+}
+
 // w [K][N] f32 -> two half planes [Kpad/8][Npad][8] (hi then lo), zero padded
 __global__ __launch_bounds__(256) void pack_weights_f16x3_kernel(const float* __restrict__ w, _Float16* __restrict__ wp, int K,
                                                                  int N, int Kpad, int Npad) {
@@ -751,6 +875,36 @@ extern "C" int asr_pwconv_mfma_f16x3(const float* x, const float* w_packed, cons
                     a.h_out, a.w_out);
     }
     return launch_f16x3(a, 0, stream);
+}
+
+extern "C" int asr_pwconv_mfma_f16x3_presplit(const void* x_split, const float* w_packed, const float* bias,
+                                              const float* residual, float* y, int64_t m, int k, int n, int ldx_chunks, int ldy,
+                                              int ldres, int relu, asr_stream_t stream) {
+    ASR_REQUIRE(x_split && w_packed && y, "asr_pwconv_mfma_f16x3_presplit: null pointer");
+    ASR_REQUIRE(m > 0 && k > 0 && n > 0, "asr_pwconv_mfma_f16x3_presplit: bad shape m=%lld k=%d n=%d", (long long)m, k, n);
+    ASR_REQUIRE(ldy >= n && (!residual || ldres >= n), "asr_pwconv_mfma_f16x3_presplit: ldy / ldres < n");
+    PwArgs a{};
+    a.x = reinterpret_cast<const float*>(x_split); a.wp = w_packed; a.bias = bias; a.res = residual; a.y = y;
+    a.M = m; a.K = k; a.N = n; a.Npad = round_up(n, 128); a.Kpad = round_up(k, BK);
+    a.ldx = ldx_chunks; a.ldy = ldy; a.ldres = ldres; a.relu = relu;
+    a.taps = 1; a.cin = k; a.stride = 1; a.pad = 0; a.dil = 1;
+    ASR_REQUIRE(ldx_chunks * BK >= a.Kpad, "asr_pwconv_mfma_f16x3_presplit: ldx_chunks * 32 < ceil32(k)");
+    ASR_UNSUPPORTED(a.Npad % 256 != 0, "asr_pwconv_mfma_f16x3_presplit: ceil128(n) must be a multiple of 256 (n=%d)", n);
+    ASR_UNSUPPORTED(reinterpret_cast<uintptr_t>(x_split) & 127, "asr_pwconv_mfma_f16x3_presplit: x_split must be 128-byte aligned");
+    constexpr int bm = 256, bn = 256;
+    a.tiles_n = (int)asr_cdiv(n, bn);
+    const long long nwg = asr_cdiv(m, bm) * a.tiles_n;
+    ASR_REQUIRE(nwg <= 0x7fffffffLL, "asr_pwconv_mfma_f16x3_presplit: grid too large");
+    constexpr size_t lds = 2 * (bm * 128 + 2 * 4 * bn * 16);
+    auto kern = pw_gemm_f16x3_pre_kernel<4, 2, 2, 4>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        ASR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(512), lds, asr_stream(stream), a);
+    ASR_LAUNCH_CHECK();
+    return ASR_OK;
 }
 
 extern "C" int asr_conv3x3_mfma_f16x3(const float* x, const float* w_packed, const float* bias, float* y, int batch, int h_in,

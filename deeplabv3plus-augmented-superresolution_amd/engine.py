@@ -232,6 +232,37 @@ class DeeplabEngine:
             return out
 
         def sepconv(x, prefix, stride=1, rate=1, depth_act=False, **pw_kw):
+            pp, pd = self.p[prefix + "_pointwise"], self.p[prefix + "_depthwise"]
+            b, h, w, c = x.shape
+            ho, wo = (h, w) if stride == 1 else ((h + 2 * rate - (2 * rate + 1)) // stride + 1,
+                                                 (w + 2 * rate - (2 * rate + 1)) // stride + 1)
+            srows = 16 if ho <= 32 else 32
+            split_ok = (pp.get("fn", "").endswith("f16x3") and (-(-pp["n"] // 128) * 128) % 256 == 0 and not pw_kw.get("out_off")
+                        and pw_kw.get("sub", 1) == 1 and ((stride == 1 and rate in (1, 2)) or (stride == 2 and rate == 1))
+                        and ho % srows == 0 and c % 8 == 0 and b <= 65535 and b * ho * wo >= 256 and not os.environ.get("ASR_NO_PRESPLIT"))
+            if split_ok:
+                # depthwise writes the pointwise GEMM's A operand directly as split-f16 chunks; the GEMM takes both operands
+                # by LDS-DMA on a 256 x 256 tile (bit-identical to the f32 hand-off, see include/asr_hip.h)
+                chunks = -(-c // 32)
+                t = new((b, ho, wo, chunks * 32))
+                add("asr_dwconv3x3_nhwc_split_f16",
+                    (x.ptr, pd["w"].data_ptr(), pd["b"].data_ptr(), t.ptr, b, h, w, c, stride, rate, rate, rate, ho, wo, x.ld, chunks,
+                     int(not depth_act), int(depth_act)),
+                    "dw", 18.0 * b * ho * wo * c, 4.0 * (b * h * w * c + b * ho * wo * c + 10 * c),
+                    label=f"{prefix}_depthwise {h}x{w}x{c} s{stride} r{rate} split", out=t)
+                out, res = pw_kw.get("out"), pw_kw.get("res")
+                if out is None:
+                    out = new((b, ho, wo, pp["n"]), pad=pw_kw.get("pad_out", True))
+                m = b * ho * wo
+                add("asr_pwconv_mfma_f16x3_presplit",
+                    (t.ptr, pp["w"].data_ptr(), pp["b"].data_ptr() if pp["b"] is not None else None,
+                     res.ptr if res is not None else None, out.ptr, m, pp["k"], pp["n"], chunks, out.ld,
+                     res.ld if res is not None else 0, int(depth_act)),
+                    "pw16", 2.0 * m * pp["k"] * pp["n"],
+                    4.0 * (m * pp["k"] + m * pp["n"] * (2 if res is not None else 1) + pp["k"] * pp["n"]),
+                    label=f"{prefix}_pointwise M={m} K={pp['k']} N={pp['n']} presplit", out=out)
+                release(t)
+                return out
             t = dw(x, prefix + "_depthwise", stride, rate, pre_relu=not depth_act, post_relu=depth_act)
             y = pw(t, prefix + "_pointwise", relu=depth_act, **pw_kw)
             release(t)

@@ -367,6 +367,30 @@ def conv3x3_direct(x, w_hwio, bias, stride, pad_top, pad_left, out_hw, relu=Fals
     return y
 
 
+def dwconv3x3_split(x, w_33c, bias, stride=1, rate=1, pre_relu=False, post_relu=0):
+    """Depthwise 3x3 ('same', or the explicit symmetric pad of the stride-2 sepconvs) whose output is written as
+    split-f16 chunks for pwconv_presplit.  Returns (buffer [B*Ho*Wo, chunks, 32] float32-typed storage, (B, Ho, Wo), chunks)."""
+    b, h, w, c = x.shape
+    pad = rate
+    ho, wo = (h, w) if stride == 1 else ((h + 2 * pad - (2 * rate + 1)) // stride + 1, (w + 2 * pad - (2 * rate + 1)) // stride + 1)
+    chunks = (c + 31) // 32
+    y = torch.empty((b * ho * wo, chunks, 32), dtype=f32, device=x.device)
+    call("asr_dwconv3x3_nhwc_split_f16", ptr(x), ptr(w_33c), ptr(bias), ptr(y), b, h, w, c, stride, rate, pad, pad, ho, wo, c,
+         chunks, int(pre_relu), int(post_relu), stream_ptr())
+    return y, (b, ho, wo), chunks
+
+
+def pwconv_presplit(x_split, w_packed16, bias, k, n, chunks, out=None, residual=None, relu=0):
+    """Pointwise conv on a split-f16 operand (dwconv3x3_split); w_packed16 from pack_pw_weights_f16x3."""
+    m = x_split.shape[0]
+    if out is None:
+        out = torch.empty((m, n), dtype=f32, device=x_split.device)
+    call("asr_pwconv_mfma_f16x3_presplit", ptr(x_split), ptr(w_packed16), ptr(bias, allow_none=True),
+         ptr(residual, allow_none=True), ptr(out), m, k, n, chunks, out.shape[-1], residual.shape[-1] if residual is not None else 0,
+         int(relu), stream_ptr())
+    return out
+
+
 def aspp_dwconv3(x, w3, bias3, rates=(6, 12, 18), pre_relu=False, post_relu=True):
     """Fused three-rate ASPP depthwise: x [B,H,W,C], w3 [3,3,3,C], bias3 [3,C] -> three [B,H,W,C]."""
     b, h, w, c = x.shape

@@ -263,6 +263,26 @@ int asr_conv3x3_mfma_f16x3(const float* x, const float* w_packed, const float* b
                          int w_in, int cin, int cout, int stride, int pad, int dil, int h_out, int w_out, int ldx,
                          int ldy, int relu, asr_stream_t stream);
 
+/* --- split-f16 activations between the two halves of a separable conv ------------------------------------------
+ * The depthwise output of _SepConv_BN (model.py:478-495) is consumed only by its pointwise conv.  Written directly in
+ * the A-operand format of the split-f16 GEMM -- per pixel and per chunk of 32 channels one 128-byte line
+ * [hi(32 halfs) | lo(32 halfs)], hi = f16(v), lo = f16(v - hi): the very split asr_pwconv_mfma_f16x3 applies to the
+ * f32 value on its way into LDS, and the same number of bytes -- it lets the GEMM take both operands by LDS-DMA
+ * (no staging registers, no conversion work) on a 256 x 256 tile.  Results are bit-identical to
+ * asr_dwconv3x3_nhwc_f32 followed by asr_pwconv_mfma_f16x3.
+ *
+ * asr_dwconv3x3_nhwc_split_f16: asr_dwconv3x3_nhwc_f32 with y in that format; ldy_chunks = ceil(c / 32) chunks per
+ * pixel, channels c .. 32 * ldy_chunks - 1 are written as zeros; needs (stride 1, rate 1|2) or (stride 2, rate 1) and
+ * h_out a multiple of 16 (32 above 32 rows); y_split 128-byte aligned.
+ * asr_pwconv_mfma_f16x3_presplit: asr_pwconv_mfma_f16x3 on such an operand (m rows = pixels, ldx_chunks chunks per
+ * row); ceil128(n) must be a multiple of 256; no sub_stride. */
+int asr_dwconv3x3_nhwc_split_f16(const float* x, const float* w, const float* bias, void* y_split, int batch, int h_in,
+                                 int w_in, int c, int stride, int rate, int pad_top, int pad_left, int h_out, int w_out,
+                                 int ldx, int ldy_chunks, int pre_relu, int post_relu, asr_stream_t stream);
+int asr_pwconv_mfma_f16x3_presplit(const void* x_split, const float* w_packed, const float* bias, const float* residual,
+                                   float* y, int64_t m, int k, int n, int ldx_chunks, int ldy, int ldres, int relu,
+                                   asr_stream_t stream);
+
 /* Conv2D 3x3 for tiny cin, weights HWIO [3,3,cin,cout]: entry_flow_conv1_1, model.py:150-153
  * ('same' with stride 2 on an even input pads bottom/right only: pad_top = pad_left = 0). */
 int asr_conv3x3_direct_f32(const float* x, const float* w, const float* bias, float* y, int batch, int h_in, int w_in,

@@ -229,3 +229,32 @@ def test_gap_and_resize(dev):
     one = _rand(rng, 2, 1, 1, 256)               # image-pooling broadcast (model.py:204-205)
     got = ops.resize_bilinear(ops.to_device(one), (16, 16)).cpu().numpy()
     assert np.array_equal(got, np.broadcast_to(one, (2, 16, 16, 256)))
+
+
+@pytest.mark.parametrize("c,n,hw,stride,rate", [(728, 728, 32, 1, 1), (256, 256, 32, 2, 1), (96, 256, 16, 1, 2), (1536, 2048, 16, 1, 2)])
+def test_presplit_sepconv_is_bit_identical_to_the_f32_handoff(dev, c, n, hw, stride, rate):
+    """dw -> split-f16 chunks -> LDS-DMA GEMM (256 x 256 tile) against dw -> f32 -> split-f16 GEMM: the same hi / lo
+    halves enter the same MFMA sequence, so the outputs must be bitwise equal (tails: M, K and N not multiples of the tile)."""
+    from asr_amd import ops
+    rng = np.random.default_rng(61)
+    b = 3
+    x = ops.to_device(_rand(rng, b, hw, hw, c))
+    wd = ops.to_device(_rand(rng, 3, 3, c, scale=0.3))
+    bd = ops.to_device(_rand(rng, c, scale=0.1))
+    wk = ops.to_device(_rand(rng, c, n, scale=(1.0 / c) ** 0.5))
+    bk = ops.to_device(_rand(rng, n, scale=0.1))
+    w16 = ops.pack_pw_weights_f16x3(wk)
+    out_hw = (hw, hw) if stride == 1 else ((hw + 2 * rate - (2 * rate + 1)) // stride + 1,) * 2
+    ref_dw = ops.dwconv3x3(x, wd, bd, stride=stride, rate=rate, out_hw=out_hw, pre_relu=True, post_relu=False)
+    m = ref_dw.shape[0] * ref_dw.shape[1] * ref_dw.shape[2]
+    res = ops.to_device(_rand(rng, m, n))
+    ref = ops.pwconv(ref_dw.reshape(m, c), w16, bk, c, n, residual=res, relu=True, f16x3=True)
+    xs, (bb, ho, wo), chunks = ops.dwconv3x3_split(x, wd, bd, stride=stride, rate=rate, pre_relu=True, post_relu=0)
+    assert bb * ho * wo == m and chunks == (c + 31) // 32
+    got = ops.pwconv_presplit(xs, w16, bk, c, n, chunks, residual=res, relu=1)
+    assert torch.equal(got, ref)
+    # the split buffer itself: hi + lo reproduces the f32 depthwise output to 2^-22, padding channels are zero
+    halves = xs.view(torch.float16).reshape(m, chunks, 2, 32).float()
+    rec = (halves[:, :, 0, :] + halves[:, :, 1, :]).reshape(m, chunks * 32)
+    np.testing.assert_allclose(rec[:, :c].cpu().numpy(), ref_dw.reshape(m, c).cpu().numpy(), rtol=3e-7, atol=1e-7)
+    assert float(rec[:, c:].abs().max()) == 0.0 if chunks * 32 > c else True
