@@ -600,13 +600,19 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void pw_gemm_f16x3_pre_kernel(PwAr
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     const int KT = p.Kpad / BK;
+#ifdef ASR_GEMM_PHASE_PROFILE
+    long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long tprev = (long long)__builtin_readcyclecounter();
+#endif
     issue_tile(0, 0);
     __syncthreads();                                           // drains the DMA (vmcnt(0)) and publishes stage 0
+    PHASE_MARK(0);
     for (int kt = 0; kt < KT; ++kt) {
         const char* const st = lds + (kt & 1) * STAGE_BYTES;
         // All 8 DMA pieces of the next tile go out before the MFMAs (spreading them between the MFMA groups, or letting
         // half of the waves request theirs after their MFMAs, measured equal / 8 % slower).
         if (kt + 1 < KT) issue_tile(kt + 1, (kt + 1) & 1);     // the other stage: last read before the previous barrier
+        PHASE_MARK(1);
 #pragma unroll
         for (int s = 0; s < BK / 16; ++s) {
             const int oct = 2 * s + hh;
@@ -630,9 +636,19 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void pw_gemm_f16x3_pre_kernel(PwAr
                 }
             }
         }
+        PHASE_MARK(2);
+        PHASE_WAIT_VM();
+        PHASE_MARK(3);
         __syncthreads();                                       // next stage landed (vmcnt(0)) and everyone is done reading this one
+        PHASE_MARK(6);
     }
     pw_epilogue<WM, WN, TM, TN, true>(p, acc, smem, tile_m, tile_n, wave, lane);
+#ifdef ASR_GEMM_PHASE_PROFILE
+    PHASE_WAIT_VM();
+    PHASE_MARK(7);
+    if (tid == 0 && orig < ASR_PHASE_BLOCKS)
+        for (int i = 0; i < 8; ++i) g_phase_cycles[orig * 8 + i] = ph[i];
+#endif
 }
 
 // w [K][N] f32 -> two half planes [Kpad/8][Npad][8] (hi then lo), zero padded
@@ -896,6 +912,8 @@ extern "C" int asr_pwconv_mfma_f16x3_presplit(const void* x_split, const float* 
     const long long nwg = asr_cdiv(m, bm) * a.tiles_n;
     ASR_REQUIRE(nwg <= 0x7fffffffLL, "asr_pwconv_mfma_f16x3_presplit: grid too large");
     constexpr size_t lds = 2 * (bm * 128 + 2 * 4 * bn * 16);
+    // (a persistent one-workgroup-per-CU form that requests the next output tile's first K tile before the epilogue of the
+    // current one, staging the epilogue through a single LDS stage, measured equal: -2 % .. +4 %; not kept)
     auto kern = pw_gemm_f16x3_pre_kernel<4, 2, 2, 4>;
     static bool attr_set = false;
     if (!attr_set) {
@@ -904,6 +922,22 @@ extern "C" int asr_pwconv_mfma_f16x3_presplit(const void* x_split, const float* 
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(512), lds, asr_stream(stream), a);
     ASR_LAUNCH_CHECK();
+#ifdef ASR_GEMM_PHASE_PROFILE
+    {
+        static long long host[ASR_PHASE_BLOCKS * 8];
+        ASR_HIP_CHECK(hipDeviceSynchronize());
+        ASR_HIP_CHECK(hipMemcpyFromSymbol(host, HIP_SYMBOL(g_phase_cycles), sizeof(host)));
+        const long long nb = nwg < ASR_PHASE_BLOCKS ? nwg : ASR_PHASE_BLOCKS;
+        double mean[8] = {0};
+        for (long long b = 0; b < nb; ++b)
+            for (int i = 0; i < 8; ++i) mean[i] += (double)host[b * 8 + i] / (double)nb;
+        const int kt = a.Kpad / 32;
+        fprintf(stderr, "[phase-pre] M=%lld K=%d N=%d blocks=%lld ksteps=%d | prologue %.0f | per k-step: issue %.0f  lds+mfma %.0f  "
+                        "vmwait %.0f  barrier %.0f | epilogue (stores drained) %.0f | block total %.0f cycles\n",
+                (long long)a.M, a.K, a.N, nwg, kt, mean[0], mean[1] / kt, mean[2] / kt, mean[3] / kt, mean[6] / kt, mean[7],
+                mean[0] + mean[1] + mean[2] + mean[3] + mean[6] + mean[7]);
+    }
+#endif
     return ASR_OK;
 }
 

@@ -7,4 +7,5 @@ cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p gpurun_out
 ASR_EXTRA_HIPFLAGS=-DASR_GEMM_PHASE_PROFILE python deeplabv3plus-augmented-superresolution_amd/csrc/build.py --force > gpurun_out/gemm_phase_build.log 2>&1
 python tools/bench_gemm.py > gpurun_out/gemm_phase.log 2>&1
-grep "\[phase\]" gpurun_out/gemm_phase.log | tac | awk '!seen[$2 $3 $4]++' | tac
+python tools/bench_presplit.py >> gpurun_out/gemm_phase.log 2>&1
+grep "\[phase" gpurun_out/gemm_phase.log | tac | awk '!seen[$1 $2 $3 $4]++' | tac
