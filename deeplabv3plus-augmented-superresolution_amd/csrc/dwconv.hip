@@ -285,8 +285,9 @@ __global__ __launch_bounds__(256) void dw_stream_full_kernel(DwArgs p, int tiles
                 const bool even = (c4 & 1) == 0;
                 const u32x2 give = even ? l2 : h2;
                 u32x2 got;
-                got.x = __shfl_xor(give.x, 1, 64);
-                got.y = __shfl_xor(give.y, 1, 64);
+                // quad_perm [1,0,3,2] (v_mov_b32_dpp, no LDS crossbar trip: __shfl_xor compiles to ds_bpermute + a wait)
+                got.x = (unsigned int)__builtin_amdgcn_mov_dpp((int)give.x, 0xB1, 0xF, 0xF, true);
+                got.y = (unsigned int)__builtin_amdgcn_mov_dpp((int)give.y, 0xB1, 0xF, 0xF, true);
                 const u32x4 out = even ? u32x4{h2.x, h2.y, got.x, got.y} : u32x4{got.x, got.y, l2.x, l2.y};
                 // even lane: hi of channels ch .. ch+7 at its own hi slot; odd lane: lo of channels ch-4 .. ch+3 at the lo slot
                 _Float16* o = ysplit + (long long)(oy0 + r) * split_row_stride + (even ? 0 : 32 - 4);
