@@ -118,7 +118,10 @@ def main():
     ap.add_argument("--precision", choices=["f16x3", "f32"], default=os.environ.get("ASR_PRECISION", "f16x3"),
                     help="pointwise GEMM arithmetic: f16x3 = split-f16 MFMA with f32 accumulation (f32-grade results), "
                          "f32 = v_mfma_f32_32x32x2_f32")
-    ap.add_argument("--overlap", action="store_true", help="run the SR stage of image i on a side HIP stream under the forward pass of image i+1 (measured: no gain, the GEMM waves already fill the register file)")
+    ap.add_argument("--overlap", action="store_true", help="run the SR stage of image i on a side HIP stream under the forward pass of image i+1")
+    ap.add_argument("--lanes", type=int, default=2, help="images in flight on alternating HIP streams, each with its own "
+                    "activation pool (1 = strictly sequential; 2 = the forward pass of one image runs under the SR stage of "
+                    "the other and vice versa; results are bit-identical)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -175,8 +178,23 @@ def main():
         return path.submit_image(imgs[i % distinct], angles, shifts, gt_dev=gts[i % distinct],
                                  adam_start=D.adam_start_step(g, SR_ITERS))
 
+    def submit_lane(i):
+        g = my_globals[i]
+        angles, shifts = params[g]
+        return path.submit_lane(i % args.lanes, imgs[i % distinct], angles, shifts, gt_dev=gts[i % distinct],
+                                adam_start=D.adam_start_step(g, SR_ITERS))
+
     def run_steps(first, count):
         recs = []
+        if args.lanes > 1 and not args.overlap:
+            pending = []
+            for i in range(first, first + count):
+                pending.append(submit_lane(i))
+                if len(pending) >= args.lanes:              # keep `lanes` images in flight, collect in submission order
+                    recs.append(pending.pop(0).result()["ious"])
+            while pending:
+                recs.append(pending.pop(0).result()["ious"])
+            return recs
         if not args.overlap:
             for i in range(first, first + count):
                 recs.append(step(i)["ious"])
@@ -195,6 +213,11 @@ def main():
         if world > 1:
             torch.distributed.barrier()
 
+    for lane in range(args.lanes if not args.overlap else 1):       # every lane's launch plan and activation pool exist
+        fb = min(args.batch_size, NUM_AUG)                          # before the timed region, whatever the warm-up count
+        model.engine.plan(fb, IMG, IMG, lane)
+        if NUM_AUG % fb:
+            model.engine.plan(NUM_AUG % fb, IMG, IMG, lane)
     run_steps(0, Wm)
     torch.cuda.synchronize()
     barrier()
@@ -230,7 +253,8 @@ def main():
             "precision": args.precision,
             "images_per_gpu": K, "num_aug": NUM_AUG, "sr_iters": SR_ITERS, "forward_batch": args.batch_size,
             "parallelism": f"images sharded over {world} GPU(s), one all-gather of IoU records",
-            "overlap": "none" if not args.overlap else "SR stage of image i on a side HIP stream under the forward pass of image i+1",
+            "overlap": ("SR stage of image i on a side HIP stream under the forward pass of image i+1" if args.overlap else
+                        (f"{args.lanes} images in flight on alternating HIP streams" if args.lanes > 1 else "none")),
         },
     }
     if rank == 0:

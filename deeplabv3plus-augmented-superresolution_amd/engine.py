@@ -403,8 +403,9 @@ class DeeplabEngine:
                     out_shape=(B, sh, sw, self.classes))
         return plan
 
-    def plan(self, B, H, Wd):
-        key = (B, H, Wd)
+    def plan(self, B, H, Wd, lane=0):
+        """lane: independent activation pools for forward passes that run concurrently on different HIP streams."""
+        key = (B, H, Wd, lane)
         if key not in self._plans:
             mult = 16 if (self.backbone == "xception" and self.OS == 16) else 8
             if H % mult or Wd % mult:
@@ -428,13 +429,13 @@ class DeeplabEngine:
                 cap.append((label, out.t.view(B, -1).clone()))
         return cap
 
-    def forward(self, x_dev, profile=None):
+    def forward(self, x_dev, profile=None, lane=0):
         """x_dev: [B,H,W,3] float32 device tensor -> logits [B,H/4,W/4,classes] (a view of plan
         memory: consume or clone it before the next forward of the same shape).
         profile: optional dict kind -> [ms, flops, bytes, launches] filled with HIP-event timings."""
         B, H, Wd, c = x_dev.shape
         assert c == 3
-        plan = self.plan(B, H, Wd)
+        plan = self.plan(B, H, Wd, lane)
         xin = plan["x_in"].t
         xin.copy_(x_dev.reshape(-1))
         lib = _lib.load()

@@ -80,8 +80,9 @@ class DeeplabModel:
         self.precision = self.engine.precision
         self.device = self.engine.device
 
-    def predict_device(self, x, batch_size=16, profile=None):
-        """x: [N,H,W,3] float32 (host array or device tensor) -> device tensor [N,h,w,classes]."""
+    def predict_device(self, x, batch_size=16, profile=None, lane=0):
+        """x: [N,H,W,3] float32 (host array or device tensor) -> device tensor [N,h,w,classes].
+        lane: activation pool to use (forward passes running concurrently on different streams need different lanes)."""
         if not isinstance(x, torch.Tensor):
             x = torch.as_tensor(np.ascontiguousarray(x, dtype=np.float32))
         n, h, w, c = x.shape
@@ -90,7 +91,7 @@ class DeeplabModel:
         outs = []
         for i in range(0, n, batch_size):
             xb = x[i:i + batch_size].to(self.device, non_blocking=True).contiguous()
-            logits = self.engine.forward(xb, profile=profile)
+            logits = self.engine.forward(xb, profile=profile, lane=lane)
             if self.final_upsample:
                 logits = self._upsample(logits, (h, w))
             else:

@@ -26,6 +26,7 @@ class HotPath:
         self.th_factor = th_factor
         self.batch_size = batch_size
         self._side = None
+        self._lanes = {}
 
     def _threshold(self, target, target_max):
         if target_max is not None:
@@ -44,10 +45,10 @@ class HotPath:
         return torch.where(am == self.class_id, am, torch.zeros_like(am))
 
     # ---- stage 1 (model stream): augment -> forward -> OPM (-> standard mask) --------------------------
-    def _stage_model(self, image_dev, angles, shifts, profile=None, want_standard=True):
+    def _stage_model(self, image_dev, angles, shifts, profile=None, want_standard=True, lane=0):
         out_hw = self.sr.output_size
         copies = au.augment_on_device(image_dev, angles, shifts)
-        preds = self.model.predict_device(copies, batch_size=self.batch_size, profile=profile)
+        preds = self.model.predict_device(copies, batch_size=self.batch_size, profile=profile, lane=lane)
         del copies
         cls, mx = au.output_processing(preds, self.class_id, self.mode)
         res = {}
@@ -101,7 +102,9 @@ class HotPath:
         .result() waits for the side stream and yields the same dict as run_image."""
         main = torch.cuda.current_stream()
         if self._side is None:
-            self._side = torch.cuda.Stream()
+            # high priority: the SR stage is a chain of short launches that must slip in between the forward pass's
+            # workgroups as they retire, not queue behind a whole GEMM grid
+            self._side = torch.cuda.Stream(priority=-1)
         res, y, ymax = self._stage_model(image_dev, angles, shifts, None, want_standard)
         ready = torch.cuda.Event()
         ready.record(main)
@@ -114,6 +117,23 @@ class HotPath:
             if t is not None:
                 t.record_stream(self._side)          # allocated on the main stream, consumed on the side stream
         return _Pending(self, res, done, keep=(y, ymax, gt_dev))
+
+    def submit_lane(self, lane, image_dev, angles, shifts, gt_dev=None, adam_start=None,
+                    sr_types=("aug", "max", "mean"), want_standard=True):
+        """Two-lane pipelining: the WHOLE image (both stages) runs on the HIP stream of `lane`, with that lane's own
+        activation pool, so consecutive images submitted to alternating lanes overlap like two independent processes
+        (the forward pass of one under the SR solve, realign and reductions of the other, and vice versa).  Results
+        are bit-identical to run_image; .result() of the returned handle waits for the lane."""
+        if lane not in self._lanes:
+            self._lanes[lane] = torch.cuda.Stream()
+        stream = self._lanes[lane]
+        stream.wait_stream(torch.cuda.current_stream())        # inputs prepared on the caller's stream
+        with torch.cuda.stream(stream):
+            res, y, ymax = self._stage_model(image_dev, angles, shifts, None, want_standard, lane=lane)
+            res = self._stage_sr(res, y, ymax, angles, shifts, gt_dev, adam_start, sr_types)
+            done = torch.cuda.Event()
+            done.record(stream)
+        return _Pending(self, res, done, keep=(y, ymax, gt_dev, image_dev))
 
     def _finish(self, res):
         if "_iou_counts" in res:

@@ -118,6 +118,37 @@ def test_hot_path_config1_test_cat(dev, synthetic, golden_dir, tmp_path):
         assert d <= 1e-3, (t, d)
 
 
+def test_two_lane_pipeline_equals_sequential(dev, synthetic):
+    """Two images in flight on alternating HIP streams with separate activation pools: same masks and IoUs as run_image."""
+    from asr_amd.model import DeeplabModel
+    from asr_amd.pipeline import HotPath
+    from asr_amd.superresolution_scripts.optimizer import Optimizer
+    from asr_amd.superresolution_scripts.superresolution import Superresolution
+    from asr_amd import distributed as D, ops
+    rng = np.random.default_rng(33)
+    size, n_aug, iters = 128, 6, 8
+    model = DeeplabModel(synthetic, (size, size, 3), 21, False, None)
+    imgs = [ops.to_device(rng.random((size, size, 3), dtype=np.float32)) for _ in range(4)]
+    gts = [ops.to_device(rng.choice(np.array([0, 8], np.int32), size=(size, size)), torch.int32) for _ in range(4)]
+    params = D.replay_augmentation_stream(4, n_aug, 0.15, 20)
+
+    def make():
+        opt = Optimizer("adam", 1e-3, amsgrad=True, lr_scheduler=True, decay_steps=60, decay_rate=0.3)
+        sr = Superresolution(1.0, 0.3, 0.7, 0.0, num_iter=iters, num_aug=n_aug, optimizer=opt, feature_size=(size // 4,) * 2,
+                             output_size=(size, size))
+        return HotPath(model, sr, class_id=8, mode="argmax", th_factor=0.15, batch_size=n_aug)
+
+    seq_path, lane_path = make(), make()
+    seq = [seq_path.run_image(imgs[i], *params[i], gt_dev=gts[i], adam_start=D.adam_start_step(i, iters)) for i in range(4)]
+    handles = [lane_path.submit_lane(i % 2, imgs[i], *params[i], gt_dev=gts[i], adam_start=D.adam_start_step(i, iters))
+               for i in range(4)]
+    for a, h in zip(seq, handles):
+        b = h.result()
+        for k in ("standard", "aug", "max", "mean"):
+            assert torch.equal(a[k], b[k]), k
+        np.testing.assert_array_equal(a["ious"], b["ious"])
+
+
 def test_pipelined_submit_equals_sequential(dev, synthetic):
     """The side-stream pipeline (SR of image i under the forward pass of image i+1) must give exactly the
     masks and IoUs of the sequential path."""
