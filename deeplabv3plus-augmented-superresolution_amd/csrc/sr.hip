@@ -179,7 +179,9 @@ __global__ __launch_bounds__(256) void sr_backward_adam_kernel(
     const int H = d.H, W = d.W, f = d.f, lw = d.w, lh = d.h;
     const int ph0 = f / 2 - 1, ph1 = f / 2;
 
-    for (int n = grp; n < d.n; n += kBwdSplit) {
+    // Two copies per trip: two independent instruction streams for the compiler to interleave (and to pair in packed
+    // f32 math where it can) in a loop that is bound by VALU issue, not by memory.
+    auto contribution = [&](int n) -> float {
         float g_df = 0.0f;
         const int bn = b * d.n + n;
         const float* r = resid + (int64_t)bn * lh * lw;
@@ -265,8 +267,15 @@ __global__ __launch_bounds__(256) void sr_backward_adam_kernel(
             };
             g_df += asr_tf_sample(ir, rd_gr, X, Y);
         }
-        contrib[n * kBwdPix + pix] = g_df;
+        return g_df;
+    };
+    int n = grp;
+    for (; n + kBwdSplit < d.n; n += 2 * kBwdSplit) {
+        const float g0 = contribution(n), g1 = contribution(n + kBwdSplit);
+        contrib[n * kBwdPix + pix] = g0;
+        contrib[(n + kBwdSplit) * kBwdPix + pix] = g1;
     }
+    if (n < d.n) contrib[n * kBwdPix + pix] = contribution(n);
     __syncthreads();
     if (grp != 0 || !in_image) return;
     float g_df = 0.0f;
