@@ -22,10 +22,16 @@ def _dev(t):
 
 
 def to_device(a, dtype=f32, device=None):
+    """Host array -> device tensor on the CURRENT stream.  Small parameter arrays (transform vectors, step sizes) go
+    through pinned memory with a non-blocking copy: a pageable copy makes the host wait for everything already queued
+    on the stream (e.g. a whole forward pass), which would serialise the lanes of the pipelined hot path."""
     device = device or _lib.require_gpu()
     if isinstance(a, torch.Tensor):
         return a.to(device=device, dtype=dtype).contiguous()
-    return torch.as_tensor(np.ascontiguousarray(a), dtype=dtype).to(device)
+    t = torch.as_tensor(np.ascontiguousarray(a), dtype=dtype)
+    if t.numel() * t.element_size() <= (1 << 20):
+        return t.pin_memory().to(device, non_blocking=True)      # the caching host allocator keeps the staging buffer alive
+    return t.to(device)
 
 
 # ---------------------------------------------------------------------------------------------
