@@ -388,6 +388,9 @@ struct AsppArgs {
     int pre_relu, post_relu;
 };
 
+// SPLIT: the three outputs in the split-f16 operand format (see dw_stream_full_kernel); a workgroup's 32 channels are
+// exactly one chunk, ldy = chunks per pixel; c % 32 == 0.
+template <bool SPLIT>
 __global__ __launch_bounds__(ATHREADS) void aspp_dw3_kernel(AsppArgs p) {
     extern __shared__ __attribute__((aligned(16))) float plane[];  // [h*w][ACB]
     const int tid = threadIdx.x;
@@ -445,7 +448,29 @@ __global__ __launch_bounds__(ATHREADS) void aspp_dw3_kernel(AsppArgs p) {
                 }
             }
             acc = post_act4(acc, p.post_relu);
-            *reinterpret_cast<f32x4*>(yout + (long long)pix * p.ldy) = acc;
+            if (SPLIT) {
+                f16x4 hi, lo;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const _Float16 h = (_Float16)acc[e];
+                    hi[e] = h;
+                    lo[e] = (_Float16)(acc[e] - (float)h);
+                }
+                typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+                typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+                const u32x2 h2 = __builtin_bit_cast(u32x2, hi), l2 = __builtin_bit_cast(u32x2, lo);
+                const bool even = (c4 & 1) == 0;
+                const u32x2 give = even ? l2 : h2;
+                u32x2 got;
+                got.x = (unsigned int)__builtin_amdgcn_mov_dpp((int)give.x, 0xB1, 0xF, 0xF, true);
+                got.y = (unsigned int)__builtin_amdgcn_mov_dpp((int)give.y, 0xB1, 0xF, 0xF, true);
+                const u32x4 out = even ? u32x4{h2.x, h2.y, got.x, got.y} : u32x4{got.x, got.y, l2.x, l2.y};
+                _Float16* o = reinterpret_cast<_Float16*>(p.y[br]) + (((long long)b * hw + pix) * p.ldy + (cb >> 5)) * 64 +
+                              (even ? c4 * 4 : 32 + (c4 - 1) * 4);
+                *reinterpret_cast<u32x4*>(o) = out;
+            } else {
+                *reinterpret_cast<f32x4*>(yout + (long long)pix * p.ldy) = acc;
+            }
         }
     }
 }
@@ -595,29 +620,50 @@ extern "C" int asr_dwconv3x3_nhwc_split_f16(const float* x, const float* w, cons
     return ASR_OK;
 }
 
-extern "C" int asr_aspp_dwconv3_nhwc_f32(const float* x, const float* w3, const float* bias3, float* y0, float* y1,
-                                         float* y2, int batch, int h, int w, int c, int rate0, int rate1, int rate2,
-                                         int ldx, int ldy, int pre_relu, int post_relu, asr_stream_t stream) {
-    ASR_REQUIRE(x && w3 && bias3 && y0 && y1 && y2, "asr_aspp_dwconv3_nhwc_f32: null pointer");
-    ASR_REQUIRE(batch > 0 && batch <= 65535 && h > 0 && w > 0 && c > 0 && rate0 > 0 && rate1 > 0 && rate2 > 0 && ldx >= c && ldy >= c,
-                "asr_aspp_dwconv3_nhwc_f32: bad geometry");
-    ASR_UNSUPPORTED((c & 3) || (ldx & 3) || (ldy & 3), "asr_aspp_dwconv3_nhwc_f32: c, ldx, ldy must be multiples of 4");
-    ASR_UNSUPPORTED((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y0) | reinterpret_cast<uintptr_t>(y1) |
-                     reinterpret_cast<uintptr_t>(y2) | reinterpret_cast<uintptr_t>(w3) | reinterpret_cast<uintptr_t>(bias3)) & 15,
-                    "asr_aspp_dwconv3_nhwc_f32: pointers must be 16-byte aligned");
+static int aspp_common(bool split, const float* x, const float* w3, const float* bias3, void* y0, void* y1, void* y2, int batch,
+                       int h, int w, int c, int rate0, int rate1, int rate2, int ldx, int ldy, int pre_relu, int post_relu,
+                       asr_stream_t stream) {
+    ASR_REQUIRE(x && w3 && bias3 && y0 && y1 && y2, "asr_aspp_dwconv3: null pointer");
+    ASR_REQUIRE(batch > 0 && batch <= 65535 && h > 0 && w > 0 && c > 0 && rate0 > 0 && rate1 > 0 && rate2 > 0 && ldx >= c &&
+                    (split ? ldy * 32 : ldy) >= c,
+                "asr_aspp_dwconv3: bad geometry");
+    ASR_UNSUPPORTED((c & 3) || (ldx & 3) || (!split && (ldy & 3)), "asr_aspp_dwconv3: c, ldx, ldy must be multiples of 4");
+    ASR_UNSUPPORTED(split && (c & 31), "asr_aspp_dwconv3_nhwc_split_f16: c must be a multiple of 32 (got %d)", c);
+    ASR_UNSUPPORTED((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w3) | reinterpret_cast<uintptr_t>(bias3)) & 15,
+                    "asr_aspp_dwconv3: x, w3, bias3 must be 16-byte aligned");
+    ASR_UNSUPPORTED((reinterpret_cast<uintptr_t>(y0) | reinterpret_cast<uintptr_t>(y1) | reinterpret_cast<uintptr_t>(y2)) & (split ? 127 : 15),
+                    "asr_aspp_dwconv3: outputs must be 16-byte (split: 128-byte) aligned");
     const size_t lds = sizeof(float) * (size_t)h * w * ACB;
-    ASR_UNSUPPORTED(lds > 160 * 1024, "asr_aspp_dwconv3_nhwc_f32: %dx%d plane x %d channels (%zu B) exceeds the 160 KB LDS; "
+    ASR_UNSUPPORTED(lds > 160 * 1024, "asr_aspp_dwconv3: %dx%d plane x %d channels (%zu B) exceeds the 160 KB LDS; "
                     "use asr_dwconv3x3_nhwc_f32 per branch", h, w, ACB, lds);
     static bool attr_set = false;
     if (!attr_set) {
-        ASR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(aspp_dw3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        ASR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(aspp_dw3_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        ASR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(aspp_dw3_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
     AsppArgs p{};
-    p.x = x; p.w = w3; p.bias = bias3; p.y[0] = y0; p.y[1] = y1; p.y[2] = y2;
+    p.x = x; p.w = w3; p.bias = bias3;
+    p.y[0] = static_cast<float*>(y0); p.y[1] = static_cast<float*>(y1); p.y[2] = static_cast<float*>(y2);
     p.batch = batch; p.h = h; p.w_ = w; p.c = c; p.rate[0] = rate0; p.rate[1] = rate1; p.rate[2] = rate2;
     p.ldx = ldx; p.ldy = ldy; p.pre_relu = pre_relu; p.post_relu = post_relu;
-    hipLaunchKernelGGL(aspp_dw3_kernel, dim3((unsigned)asr_cdiv(c, ACB), batch), dim3(ATHREADS), lds, asr_stream(stream), p);
+    const dim3 grid((unsigned)asr_cdiv(c, ACB), batch);
+    if (split) hipLaunchKernelGGL(aspp_dw3_kernel<true>, grid, dim3(ATHREADS), lds, asr_stream(stream), p);
+    else hipLaunchKernelGGL(aspp_dw3_kernel<false>, grid, dim3(ATHREADS), lds, asr_stream(stream), p);
     ASR_LAUNCH_CHECK();
     return ASR_OK;
+}
+
+extern "C" int asr_aspp_dwconv3_nhwc_f32(const float* x, const float* w3, const float* bias3, float* y0, float* y1,
+                                         float* y2, int batch, int h, int w, int c, int rate0, int rate1, int rate2,
+                                         int ldx, int ldy, int pre_relu, int post_relu, asr_stream_t stream) {
+    return aspp_common(false, x, w3, bias3, y0, y1, y2, batch, h, w, c, rate0, rate1, rate2, ldx, ldy, pre_relu, post_relu, stream);
+}
+
+// asr_aspp_dwconv3_nhwc_f32 with the three outputs as split-f16 GEMM operands (ldy_chunks = c / 32 chunks per pixel).
+extern "C" int asr_aspp_dwconv3_nhwc_split_f16(const float* x, const float* w3, const float* bias3, void* y0, void* y1, void* y2,
+                                               int batch, int h, int w, int c, int rate0, int rate1, int rate2, int ldx,
+                                               int ldy_chunks, int pre_relu, int post_relu, asr_stream_t stream) {
+    return aspp_common(true, x, w3, bias3, y0, y1, y2, batch, h, w, c, rate0, rate1, rate2, ldx, ldy_chunks, pre_relu, post_relu,
+                       stream);
 }

@@ -369,13 +369,24 @@ class DeeplabEngine:
             # 32-channel plane in LDS once (input read from HBM 1x instead of 3x)
             ts = [new((b, fh, fw, fc)) for _ in rates]
             p3 = self.p["aspp_dw3"]
-            add("asr_aspp_dwconv3_nhwc_f32",
+            split = (all(self.p[f"aspp{i + 1}_pointwise"].get("fn", "").endswith("f16x3") for i in range(3)) and fc % 32 == 0
+                     and b * fh * fw >= 256 and not os.environ.get("ASR_NO_PRESPLIT"))
+            add("asr_aspp_dwconv3_nhwc_split_f16" if split else "asr_aspp_dwconv3_nhwc_f32",
                 (x.ptr, p3["w"].data_ptr(), p3["b"].data_ptr(), ts[0].ptr, ts[1].ptr, ts[2].ptr, b, fh, fw, fc,
-                 rates[0], rates[1], rates[2], x.ld, ts[0].ld, 0, 1),
+                 rates[0], rates[1], rates[2], x.ld, fc // 32 if split else ts[0].ld, 0, 1),
                 "dw", 3 * 18.0 * b * fh * fw * fc, 3 * 4.0 * 2 * b * fh * fw * fc,
-                label=f"aspp_dw3 {fh}x{fw}x{fc} r{rates[0]}/{rates[1]}/{rates[2]} fused", out=ts[0])
+                label=f"aspp_dw3 {fh}x{fw}x{fc} r{rates[0]}/{rates[1]}/{rates[2]} fused" + (" split" if split else ""), out=ts[0])
             for i, t in enumerate(ts):
-                pw(t, f"aspp{i + 1}_pointwise", out=cat, out_off=512 + 256 * i, relu=True)
+                if split:
+                    pp = self.p[f"aspp{i + 1}_pointwise"]
+                    m = b * fh * fw
+                    add("asr_pwconv_mfma_f16x3_presplit",
+                        (t.ptr, pp["w"].data_ptr(), pp["b"].data_ptr(), None, cat.ptr + 4 * (512 + 256 * i), m, pp["k"], pp["n"],
+                         fc // 32, cat.ld, 0, 1),
+                        "pw16", 2.0 * m * pp["k"] * pp["n"], 4.0 * (m * pp["k"] + m * pp["n"] + pp["k"] * pp["n"]),
+                        label=f"aspp{i + 1}_pointwise M={m} K={pp['k']} N={pp['n']} presplit", out=cat)
+                else:
+                    pw(t, f"aspp{i + 1}_pointwise", out=cat, out_off=512 + 256 * i, relu=True)
                 release(t)
         else:
             for i, rate in enumerate(rates):

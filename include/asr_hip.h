@@ -283,6 +283,11 @@ int asr_pwconv_mfma_f16x3_presplit(const void* x_split, const float* w_packed, c
                                    float* y, int64_t m, int k, int n, int ldx_chunks, int ldy, int ldres, int relu,
                                    asr_stream_t stream);
 
+/* asr_aspp_dwconv3_nhwc_f32 with its three outputs as split-f16 operands (ldy_chunks = c / 32; c % 32 == 0). */
+int asr_aspp_dwconv3_nhwc_split_f16(const float* x, const float* w3, const float* bias3, void* y0, void* y1, void* y2,
+                                    int batch, int h, int w, int c, int rate0, int rate1, int rate2, int ldx,
+                                    int ldy_chunks, int pre_relu, int post_relu, asr_stream_t stream);
+
 /* Conv2D 3x3 for tiny cin, weights HWIO [3,3,cin,cout]: entry_flow_conv1_1, model.py:150-153
  * ('same' with stride 2 on an even input pads bottom/right only: pad_top = pad_left = 0). */
 int asr_conv3x3_direct_f32(const float* x, const float* w, const float* bias, float* y, int batch, int h_in, int w_in,
