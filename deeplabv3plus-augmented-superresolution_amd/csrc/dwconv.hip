@@ -252,7 +252,8 @@ __global__ __launch_bounds__(256) void dw_stream_full_kernel(DwArgs p, int tiles
     for (int j = 0; j < PF; ++j)
 #pragma unroll
         for (int t = 0; t < S; ++t) issue(base0 + WIN - S + j * S + t, q[j][t]);
-    for (int r0 = 0; r0 < SROWS; r0 += PF) {
+#pragma unroll
+    for (int r0 = 0; r0 < SROWS; r0 += PF) {       // fully unrolled: window "shifts" become register renaming
 #pragma unroll
         for (int j = 0; j < PF; ++j) {
             const int r = r0 + j;
