@@ -80,3 +80,24 @@ def test_robustness_grid_script(dev, golden_dir, tmp_path):
     rows = list(csv.reader(open(tmp_path / "rob" / "robustness_1_class_all_small.csv")))
     assert rows[0] == ["Angle", "Shift_X", "Shift_Y", "mIoU"] and len(rows) == 9
     assert all(0.0 <= float(r[3]) <= 1.0 for r in rows[1:])
+
+
+def test_bench_contract_line(dev):
+    """bench.py prints ONE JSON line with the driver's keys, the roofline of the dominant kernel and the CPU baseline
+    (a short run: 3 steps, bounded oracle sample)."""
+    import json
+    out = _run([os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "2"], ROOT)
+    lines = [l for l in out.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["steps"] == 3 and d["warmup"] == 2 and d["n_gpus"] == 1 and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["value"] > 50 and abs(d["value"] - 100 * 1000.0 / d["ms_per_step"]) < 1e-3 * d["value"]   # 100 copies per step
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and "traffic" in r
+    assert d["roofline_depthwise"]["bound"] == "hbm" and 0.3 < d["roofline_depthwise"]["frac"] < 1.0
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1 and "sample" in c
+    assert "workload" in d["config"] and "model" not in d["config"]
