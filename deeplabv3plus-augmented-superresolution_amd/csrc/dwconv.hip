@@ -188,7 +188,10 @@ __global__ __launch_bounds__(256) void dw_stream_kernel(DwArgs p, int tiles_x) {
 // then the number of chunks per pixel; channels c .. 32 * ldy - 1 are written as zeros (the GEMM reads whole chunks).
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
-template <int R, int S, int SROWS, int PF, bool SPLIT>
+// ACT: 0 = activations from the runtime flags, 1 = pre-ReLU only (the sepconvs without depth activation), 2 = post-ReLU
+// only (with depth activation) -- at ~5 TB/s these kernels are bound by VALU issue (3 waves per SIMD, ~150 instructions
+// per output row), and a runtime flag costs a v_max + v_cndmask per loaded element instead of one v_max.
+template <int R, int S, int SROWS, int PF, bool SPLIT, int ACT>
 __global__ __launch_bounds__(256) void dw_stream_full_kernel(DwArgs p, int tiles_x) {
     constexpr int WIN = 2 * R + 1;
     static_assert(SROWS % PF == 0, "strip length must be a multiple of the prefetch depth");
@@ -216,16 +219,23 @@ __global__ __launch_bounds__(256) void dw_stream_full_kernel(DwArgs p, int tiles
     if (ch >= p.c || ox >= p.w_out) return;
     const float* xin = p.x + (long long)b * p.h_in * p.w_in * p.ldx + ch;
     float* yout = p.y + ((long long)b * p.h_out * p.w_out + ox) * p.ldy + ch;
-    f32x4 wk[9];
-#pragma unroll
-    for (int t = 0; t < 9; ++t) wk[t] = *reinterpret_cast<const f32x4*>(p.w + (long long)t * p.c + ch);
-    const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + ch);
     const int ixl = ox * S - p.pad_left, ixc = ixl + R, ixr = ixl + 2 * R;
     const bool vl = ixl >= 0 && ixl < p.w_in, vc = ixc >= 0 && ixc < p.w_in, vr = ixr >= 0 && ixr < p.w_in;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    // a tap column outside the image (left / right zero padding) is switched off in the WEIGHTS, once per thread, instead
+    // of zeroing the (clamped, finite) loaded values row by row
+    f32x4 wk[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const bool col_ok = (t % 3 == 0) ? vl : ((t % 3 == 1) ? vc : vr);
+        const f32x4 wv = *reinterpret_cast<const f32x4*>(p.w + (long long)t * p.c + ch);
+        wk[t] = col_ok ? wv : zero;
+    }
+    const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + ch);
     const long long ofl = (long long)min(max(ixl, 0), p.w_in - 1) * p.ldx, ofc = (long long)min(max(ixc, 0), p.w_in - 1) * p.ldx,
                     ofr = (long long)min(max(ixr, 0), p.w_in - 1) * p.ldx;
     const long long row_stride = (long long)p.w_in * p.ldx;
-    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    const bool pre = ACT == 0 ? p.pre_relu != 0 : ACT == 1;
 
     auto issue = [&](int iy, f32x4 (&d)[3]) {                 // three unconditional loads from a clamped row
         const float* row = xin + (long long)min(max(iy, 0), p.h_in - 1) * row_stride;
@@ -233,11 +243,15 @@ __global__ __launch_bounds__(256) void dw_stream_full_kernel(DwArgs p, int tiles
         d[1] = *reinterpret_cast<const f32x4*>(row + ofc);
         d[2] = *reinterpret_cast<const f32x4*>(row + ofr);
     };
-    auto enter = [&](int iy, const f32x4 (&d)[3], f32x4 (&w)[3]) {   // zero padding + pre-activation at window entry
-        const bool vy = iy >= 0 && iy < p.h_in;
-        w[0] = (vy && vl) ? (p.pre_relu ? relu4(d[0]) : d[0]) : zero;
-        w[1] = (vy && vc) ? (p.pre_relu ? relu4(d[1]) : d[1]) : zero;
-        w[2] = (vy && vr) ? (p.pre_relu ? relu4(d[2]) : d[2]) : zero;
+    auto enter = [&](int iy, const f32x4 (&d)[3], f32x4 (&w)[3]) {   // top / bottom zero padding + pre-activation at window entry
+        // the row index is the same for the whole workgroup: a scalar branch in the (rare) padding rows, nothing otherwise
+        const int vy = __builtin_amdgcn_readfirstlane((int)(iy >= 0 && iy < p.h_in));
+#pragma unroll
+        for (int k = 0; k < 3; ++k) w[k] = (ACT == 1) ? relu4(d[k]) : ((ACT == 2) ? d[k] : (pre ? relu4(d[k]) : d[k]));
+        if (!vy) {
+            asm volatile("" ::: "memory");                     // keeps this a branch (if-conversion would put 12 v_cndmask on every row)
+            w[0] = zero; w[1] = zero; w[2] = zero;
+        }
     };
 
     f32x4 win[WIN][3], q[PF][S][3];
@@ -268,7 +282,8 @@ __global__ __launch_bounds__(256) void dw_stream_full_kernel(DwArgs p, int tiles
             for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx) acc += win[ky * R][kx] * wk[ky * 3 + kx];
-            acc = post_act4(acc, p.post_relu);
+            if (ACT == 2) acc = relu4(acc);
+            else if (ACT == 0) acc = post_act4(acc, p.post_relu);
             if (SPLIT) {
                 f16x4 hi, lo;
 #pragma unroll
@@ -512,21 +527,24 @@ __global__ __launch_bounds__(256) void dw_direct_kernel(DwArgs p) {
 template <int R, int S>
 int launch_stream(const DwArgs& p, hipStream_t s, bool split = false) {
     static const int srows_env = getenv("ASR_DW_SROWS") ? atoi(getenv("ASR_DW_SROWS")) : 0;
-    static const int pf_env = getenv("ASR_DW_PF") ? atoi(getenv("ASR_DW_PF")) : 0;
+    static const int generic_env = getenv("ASR_DW_GENERIC") ? atoi(getenv("ASR_DW_GENERIC")) : 0;
     const int tiles_x = (int)asr_cdiv(p.w_out, SCOLS), chunks = (int)asr_cdiv(p.c, 64);
     const int srows = srows_env ? srows_env : (p.h_out <= 32 ? 16 : 32);
     const dim3 grid(tiles_x * chunks, (unsigned)asr_cdiv(p.h_out, srows), p.batch);
     // full strips (every layer of the net): the branch-free kernel; 4 rows in flight on the small OS16 maps (few waves
-    // per image), 1 on the large ones (measured).  ASR_DW_PF = 1 | 2 | 4 overrides, -1 = generic kernel.
-    const int pf = pf_env ? pf_env : (p.h_out <= 32 ? 4 : 1);
-    if (pf > 0 && p.h_out % srows == 0 && (srows == 16 || srows == 32)) {
-#define ASR_DW_FULL(SR_, PF_)                                                                                              \
-    do {                                                                                                                   \
-        if (split) hipLaunchKernelGGL((dw_stream_full_kernel<R, S, SR_, PF_, true>), grid, dim3(256), 0, s, p, tiles_x);    \
-        else hipLaunchKernelGGL((dw_stream_full_kernel<R, S, SR_, PF_, false>), grid, dim3(256), 0, s, p, tiles_x);         \
+    // per image), 1 on the large ones (measured); the two activation patterns of the Xception sepconvs are
+    // compiled in for the 16-row strips (the middle flow).  ASR_DW_GENERIC=1 selects the generic kernel (A/B runs).
+    if (!generic_env && p.h_out % srows == 0 && (srows == 16 || srows == 32)) {
+        const int act = (srows == 16) ? ((p.pre_relu == 1 && p.post_relu == 0) ? 1 : ((p.pre_relu == 0 && p.post_relu == 1) ? 2 : 0)) : 0;
+#define ASR_DW_FULL(SR_, PF_, ACT_)                                                                                              \
+    do {                                                                                                                         \
+        if (split) hipLaunchKernelGGL((dw_stream_full_kernel<R, S, SR_, PF_, true, ACT_>), grid, dim3(256), 0, s, p, tiles_x);    \
+        else hipLaunchKernelGGL((dw_stream_full_kernel<R, S, SR_, PF_, false, ACT_>), grid, dim3(256), 0, s, p, tiles_x);         \
     } while (0)
-        if (srows == 16) { if (pf == 1) ASR_DW_FULL(16, 1); else if (pf == 2) ASR_DW_FULL(16, 2); else ASR_DW_FULL(16, 4); }
-        else { if (pf == 1) ASR_DW_FULL(32, 1); else if (pf == 2) ASR_DW_FULL(32, 2); else ASR_DW_FULL(32, 4); }
+        if (srows == 32) ASR_DW_FULL(32, 1, 0);
+        else if (act == 1) ASR_DW_FULL(16, 4, 1);
+        else if (act == 2) ASR_DW_FULL(16, 4, 2);
+        else ASR_DW_FULL(16, 4, 0);
 #undef ASR_DW_FULL
         return ASR_OK;
     }
