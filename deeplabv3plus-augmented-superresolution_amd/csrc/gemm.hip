@@ -44,7 +44,7 @@ struct PwArgs {
     int taps;  // 1 = pointwise (optionally spatially subsampled), 9 = 3x3 implicit GEMM
     int cin;   // channels per tap
     int h_in, w_in, h_out, w_out, stride, pad, dil;
-    int debug;  // bit0: skip epilogue stores (timing experiments only)
+    int debug;  // timing experiments only (ASR_GEMM_DEBUG): bit0 skip the epilogue, bit3 skip the MFMA section (pre-split kernel)
 };
 
 // ---- epilogue shared by the f32 and the split-f16 kernels ------------------------------------------
@@ -613,6 +613,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void pw_gemm_f16x3_pre_kernel(PwAr
         // half of the waves request theirs after their MFMAs, measured equal / 8 % slower).
         if (kt + 1 < KT) issue_tile(kt + 1, (kt + 1) & 1);     // the other stage: last read before the previous barrier
         PHASE_MARK(1);
+        if (!(p.debug & 8))
 #pragma unroll
         for (int s = 0; s < BK / 16; ++s) {
             const int oct = 2 * s + hh;
@@ -642,7 +643,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void pw_gemm_f16x3_pre_kernel(PwAr
         __syncthreads();                                       // next stage landed (vmcnt(0)) and everyone is done reading this one
         PHASE_MARK(6);
     }
-    pw_epilogue<WM, WN, TM, TN, true>(p, acc, smem, tile_m, tile_n, wave, lane);
+    if (!(p.debug & 1)) pw_epilogue<WM, WN, TM, TN, true>(p, acc, smem, tile_m, tile_n, wave, lane);
+    else if (acc[0][0][0] == 12345.678f) p.y[0] = acc[1][3][5] + acc[0][1][2];
 #ifdef ASR_GEMM_PHASE_PROFILE
     PHASE_WAIT_VM();
     PHASE_MARK(7);
@@ -908,6 +910,8 @@ extern "C" int asr_pwconv_mfma_f16x3_presplit(const void* x_split, const float* 
     ASR_UNSUPPORTED(a.Npad % 256 != 0, "asr_pwconv_mfma_f16x3_presplit: ceil128(n) must be a multiple of 256 (n=%d)", n);
     ASR_UNSUPPORTED(reinterpret_cast<uintptr_t>(x_split) & 127, "asr_pwconv_mfma_f16x3_presplit: x_split must be 128-byte aligned");
     constexpr int bm = 256, bn = 256;
+    static const int dbg = getenv("ASR_GEMM_DEBUG") ? atoi(getenv("ASR_GEMM_DEBUG")) : 0;
+    a.debug = dbg;
     a.tiles_n = (int)asr_cdiv(n, bn);
     const long long nwg = asr_cdiv(m, bm) * a.tiles_n;
     ASR_REQUIRE(nwg <= 0x7fffffffLL, "asr_pwconv_mfma_f16x3_presplit: grid too large");

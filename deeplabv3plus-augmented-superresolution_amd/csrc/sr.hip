@@ -154,133 +154,14 @@ __device__ __forceinline__ SrAxisTap sr_axis_tap(int c, float shift, int size, i
     return a;
 }
 
-// Work split: a workgroup owns 64 HR pixels (32 x 2) and NSPLIT = 4 waves; wave g evaluates the copies
-// n = g, g + 4, ... for those pixels (the copy index is wave-uniform, so the transforms are scalar loads)
-// and parks each contribution in LDS as contrib[n][pixel]; after one barrier wave 0 adds the N
-// contributions IN COPY ORDER (the summation order of the oracle, so results stay bit-identical) and
-// applies the priors and the Adam update.  4x the exposed parallelism of a one-thread-per-pixel loop for a
-// latency-bound gather, N * 256 bytes of LDS.
-constexpr int kBwdSplit = 4, kBwdPixX = 32, kBwdPixY = 2, kBwdPix = kBwdPixX * kBwdPixY;
-
-template <int LOG2F>
-__global__ __launch_bounds__(256) void sr_backward_adam_kernel(
-    const float* __restrict__ x, float* __restrict__ x_new, const float* __restrict__ resid,
-    const float* __restrict__ inv_rot_tf, const float* __restrict__ inv_trans_tf,
-    float* __restrict__ m, float* __restrict__ v, float* __restrict__ vhat,
-    const float* __restrict__ alphas /* [batch] for this iteration */, float* __restrict__ grad_out,
-    SrDims d, float two_lambda_df, float lambda_tv, float two_lambda_l2, float lambda_l1, SrStep st) {
-    extern __shared__ float contrib[];                     // [n][kBwdPix]
-    const int X = blockIdx.x * kBwdPixX + threadIdx.x;
-    const int Y = blockIdx.y * kBwdPixY + threadIdx.y;
-    const int b = blockIdx.z;
-    const int grp = threadIdx.z;                           // copy group == wave index
-    const int pix = threadIdx.y * kBwdPixX + threadIdx.x;
-    const bool in_image = (X < d.W) & (Y < d.H);
-    const int H = d.H, W = d.W, f = d.f, lw = d.w, lh = d.h;
-    const int ph0 = f / 2 - 1, ph1 = f / 2;
-
-    // Two copies per trip: two independent instruction streams for the compiler to interleave (and to pair in packed
-    // f32 math where it can) in a loop that is bound by VALU issue, not by memory.
-    auto contribution = [&](int n) -> float {
-        float g_df = 0.0f;
-        const int bn = b * d.n + n;
-        const float* r = resid + (int64_t)bn * lh * lw;
-        const AsrTf8 ir = asr_load_tf(inv_rot_tf + (int64_t)bn * 8);
-        const AsrTf8 it = asr_load_tf(inv_trans_tf + (int64_t)bn * 8);
-        auto gt_at = [&](int ly, int lx) -> float {   // branch-free: clamped index, unconditional load, select
-            const bool ok = (ly >= 0) & (lx >= 0);
-            const float v = (two_lambda_df * r[ok ? ly * lw + lx : 0]) * 0.25f;
-            return ok ? v : 0.0f;
-        };
-        const bool pure_translation = (it.a0 == 1.0f && it.a1 == 0.0f && it.b0 == 0.0f && it.b1 == 1.0f &&
-                                       it.c0 == 0.0f && it.c1 == 0.0f);
-        if (pure_translation) {
-            // rotation stage (generic affine), then the separable translate stage
-            float ix, iy;
-            asr_tf_map(ir, (float)X, (float)Y, ix, iy);
-            const float xf = floorf(ix), yf = floorf(iy);
-            const int x0 = asr_coord_to_int(xf), y0 = asr_coord_to_int(yf);
-            const SrAxisTap ax0 = sr_axis_tap<LOG2F>(x0, it.a2, W, f, ph0, ph1);
-            const SrAxisTap ax1 = sr_axis_tap<LOG2F>(x0 + 1, it.a2, W, f, ph0, ph1);
-            const SrAxisTap ay0 = sr_axis_tap<LOG2F>(y0, it.b2, H, f, ph0, ph1);
-            const SrAxisTap ay1 = sr_axis_tap<LOG2F>(y0 + 1, it.b2, H, f, ph0, ph1);
-            // The 4 x 4 G_T taps under this pixel sit on 3 consecutive HR positions per axis, i.e. on at most
-            // 2 x 2 distinct LR residual cells: load those four values once and let every tap select its own
-            // (16 gathers -> 4; the texture-address path, not the VALU, bounded this kernel).
-            const int big = 0x3fffffff;
-            auto lo_of = [&](int a, int b2, int c, int e) {
-                return min(min(a >= 0 ? a : big, b2 >= 0 ? b2 : big), min(c >= 0 ? c : big, e >= 0 ? e : big));
-            };
-            const int cxa = lo_of(ax0.l0, ax0.l1, ax1.l0, ax1.l1), cxb = max(max(ax0.l0, ax0.l1), max(ax1.l0, ax1.l1));
-            const int cya = lo_of(ay0.l0, ay0.l1, ay1.l0, ay1.l1), cyb = max(max(ay0.l0, ay0.l1), max(ay1.l0, ay1.l1));
-            auto in2 = [](int l, int a, int b2) { return (l < 0) | (l == a) | (l == b2); };
-            const bool two_cells = in2(ax0.l0, cxa, cxb) & in2(ax0.l1, cxa, cxb) & in2(ax1.l0, cxa, cxb) & in2(ax1.l1, cxa, cxb) &
-                                   in2(ay0.l0, cya, cyb) & in2(ay0.l1, cya, cyb) & in2(ay1.l0, cya, cyb) & in2(ay1.l1, cya, cyb);
-            const float wxl = (xf + 1.0f) - ix, wxh = ix - xf;
-            if (two_cells) {
-                const int xa = (cxa == big) ? 0 : cxa, xb = max(cxb, 0), ya = (cya == big) ? 0 : cya, yb = max(cyb, 0);
-                const float saa = (two_lambda_df * r[ya * lw + xa]) * 0.25f, sab = (two_lambda_df * r[ya * lw + xb]) * 0.25f;
-                const float sba = (two_lambda_df * r[yb * lw + xa]) * 0.25f, sbb = (two_lambda_df * r[yb * lw + xb]) * 0.25f;
-                // The 16 taps select among the four cell values; selection and the x blend commute with the row choice,
-                // so the x blend is done ONCE per (tap column pair, cell row) and the taps only pick a row afterwards --
-                // the same products and sums on the same operands as tap-by-tap selection (an invalid tap contributes
-                // w * 0 = +0 either way), a third of the v_cndmask / compare instructions this VALU-bound loop spent.
-                auto cell = [&](int lx, float va, float vb) -> float {           // value of column lx in one cell row
-                    const float v = (lx == cxa) ? va : vb;
-                    return (lx >= 0) ? v : 0.0f;
-                };
-                auto hx = [&](const SrAxisTap& ax, float va, float vb) -> float {   // x blend of a tap column pair in one cell row
-                    return ax.wl * cell(ax.l0, va, vb) + ax.wh * cell(ax.l1, va, vb);
-                };
-                const float h0a = hx(ax0, saa, sab), h0b = hx(ax0, sba, sbb);
-                const float h1a = hx(ax1, saa, sab), h1b = hx(ax1, sba, sbb);
-                auto row = [&](int ly, float ha, float hb) -> float {              // the x-blended value of tap row ly
-                    const float v = (ly == cya) ? ha : hb;
-                    return (ly >= 0) ? v : 0.0f;
-                };
-                auto gr = [&](const SrAxisTap& ay, const SrAxisTap& ax, float ha, float hb) -> float {   // G_R at one integer position
-                    const float v = ay.wl * row(ay.l0, ha, hb) + ay.wh * row(ay.l1, ha, hb);
-                    return (ay.inb & ax.inb) ? v : 0.0f;
-                };
-                const float vyf = wxl * gr(ay0, ax0, h0a, h0b) + wxh * gr(ay0, ax1, h1a, h1b);
-                const float vyc = wxl * gr(ay1, ax0, h0a, h0b) + wxh * gr(ay1, ax1, h1a, h1b);
-                g_df += ((yf + 1.0f) - iy) * vyf + (iy - yf) * vyc;
-            } else {   // > 2 distinct cells on an axis: only through float rounding at a binade edge; 16 direct gathers
-                auto gr = [&](const SrAxisTap& ay, const SrAxisTap& ax) -> float {
-                    const float vyf = ax.wl * gt_at(ay.l0, ax.l0) + ax.wh * gt_at(ay.l0, ax.l1);
-                    const float vyc = ax.wl * gt_at(ay.l1, ax.l0) + ax.wh * gt_at(ay.l1, ax.l1);
-                    const float v = ay.wl * vyf + ay.wh * vyc;
-                    return (ay.inb & ax.inb) ? v : 0.0f;
-                };
-                const float vyf = wxl * gr(ay0, ax0) + wxh * gr(ay0, ax1);
-                const float vyc = wxl * gr(ay1, ax0) + wxh * gr(ay1, ax1);
-                g_df += ((yf + 1.0f) - iy) * vyf + (iy - yf) * vyc;
-            }
-        } else {
-            // generic projective inverse transforms (never produced by the reference's translate)
-            auto rd_gt = [&](int yt, int xt) -> float {
-                return gt_at(sr_gt_index<LOG2F>(yt, H, f, ph0, ph1), sr_gt_index<LOG2F>(xt, W, f, ph0, ph1));
-            };
-            auto rd_gr = [&](int yr, int xr) -> float {
-                if (!(yr >= 0 && yr < H && xr >= 0 && xr < W)) return 0.0f;
-                return asr_tf_sample(it, rd_gt, xr, yr);
-            };
-            g_df += asr_tf_sample(ir, rd_gr, X, Y);
-        }
-        return g_df;
-    };
-    int n = grp;
-    for (; n + kBwdSplit < d.n; n += 2 * kBwdSplit) {
-        const float g0 = contribution(n), g1 = contribution(n + kBwdSplit);
-        contrib[n * kBwdPix + pix] = g0;
-        contrib[(n + kBwdSplit) * kBwdPix + pix] = g1;
-    }
-    if (n < d.n) contrib[n * kBwdPix + pix] = contribution(n);
-    __syncthreads();
-    if (grp != 0 || !in_image) return;
-    float g_df = 0.0f;
-    for (int n = 0; n < d.n; ++n) g_df += contrib[n * kBwdPix + pix];   // fixed order n = 0..N-1
-
+// Everything after the data-term gradient of one HR pixel: prior gradients and the optimiser update (shared by the
+// fused and the gather backward kernels).
+__device__ __forceinline__ void sr_prior_and_update(const float* __restrict__ x, float* __restrict__ x_new, float* __restrict__ m,
+                                                    float* __restrict__ v, float* __restrict__ vhat,
+                                                    const float* __restrict__ alphas, float* __restrict__ grad_out,
+                                                    const SrDims& d, int b, int X, int Y, float g_df, float lambda_tv,
+                                                    float two_lambda_l2, float lambda_l1, const SrStep& st) {
+    const int H = d.H, W = d.W;
     // priors (superresolution.py:81-98): TV (forward differences, last row/col 0) or bilateral TV, L2, L1
     const float* img = x + (int64_t)b * H * W;
     const float xc = img[Y * W + X];
@@ -378,6 +259,256 @@ __global__ __launch_bounds__(256) void sr_backward_adam_kernel(
     }
 }
 
+// Work split: a workgroup owns 64 HR pixels (32 x 2) and NSPLIT = 4 waves; wave g evaluates the copies
+// n = g, g + 4, ... for those pixels (the copy index is wave-uniform, so the transforms are scalar loads)
+// and parks each contribution in LDS as contrib[n][pixel]; after one barrier wave 0 adds the N
+// contributions IN COPY ORDER (the summation order of the oracle, so results stay bit-identical) and
+// applies the priors and the Adam update.  4x the exposed parallelism of a one-thread-per-pixel loop for a
+// latency-bound gather, N * 256 bytes of LDS.
+constexpr int kBwdSplit = 4, kBwdPixX = 32, kBwdPixY = 2, kBwdPix = kBwdPixX * kBwdPixY;
+
+// Two-kernel form of the data-term gradient (asr_sr_solve_*): G_R(n, c) -- the gradient that reaches the rotation stage
+// at the integer HR position c of copy n, i.e. the registered gradient of the translate applied to G_T -- depends on
+// (n, c) only, yet the fused kernel re-derives it for each of the 4 rotation taps of every (pixel, copy) pair (16 nested
+// taps, ~250 VALU instructions per pair; the kernel is VALU-bound).  sr_grad_translate_kernel evaluates it ONCE per
+// (n, c) into a zero-bordered [batch*n, H + 4, W + 8] plane (written and re-read through L2 / the Infinity Cache: 107 MB
+// at N = 100, 512^2) and sr_backward_gather_kernel takes the rotation's 4 taps from that plane.  Same products and sums
+// on the same operands as the fused kernel (x blend, then y blend, then the rotation's bilinear weights) -> bit-identical.
+//   Plane geometry: row stride W + 8 (4 zero columns each side), 2 zero rows above and below.  A tap pair whose floor
+//   coordinate is clamped to [-2, W] x [-2, H] reads only zeros wherever the unclamped taps are out of the image, so the
+//   gather needs no per-tap bounds test and no select.
+constexpr int kGrPadX = 4, kGrPadY = 2;
+constexpr int kGrRows = 16;   // HR rows per wave of sr_grad_translate_kernel
+__host__ __device__ inline size_t sr_gr_plane_elems(int H, int W) { return (size_t)(H + 2 * kGrPadY) * (size_t)(W + 2 * kGrPadX); }
+
+// One wave: 64 columns x kGrRows rows of one copy.  The x taps are per lane (its column); the y taps of the wave's rows
+// are computed by lanes 0..kGrRows-1 in ONE pass and fetched per row with v_readlane (they are wave-uniform: scalar row
+// pointers, scalar validity branches).  The x blend of an LR row, h(L) = wl * G(L, l0) + wh * G(L, l1), serves the up
+// to 4 HR rows that tap L: a two-entry cache keyed by the (uniform) LR row index keeps the last two.
+template <int LOG2F>
+__global__ __launch_bounds__(256) void sr_grad_translate_kernel(const float* __restrict__ resid,
+                                                                const float* __restrict__ inv_trans_tf,
+                                                                float* __restrict__ gr_out, SrDims d, float two_lambda_df) {
+    const int bn = blockIdx.z;
+    const int lane = threadIdx.x;
+    const int cx = blockIdx.x * 64 + lane;
+    const int cy0 = (blockIdx.y * 4 + __builtin_amdgcn_readfirstlane(threadIdx.y)) * kGrRows;
+    const int H = d.H, W = d.W, f = d.f, lw = d.w, lh = d.h;
+    const int ph0 = f / 2 - 1, ph1 = f / 2;
+    const int WP = W + 2 * kGrPadX;
+    const float* r = resid + (int64_t)bn * lh * lw;
+    const AsrTf8 it = asr_load_tf(inv_trans_tf + (int64_t)bn * 8);
+    float* const out = gr_out + (size_t)bn * sr_gr_plane_elems(H, W) + (size_t)kGrPadY * WP + kGrPadX;
+    const bool col_ok = cx < W;
+    const bool pure_translation = (it.a0 == 1.0f && it.a1 == 0.0f && it.b0 == 0.0f && it.b1 == 1.0f &&
+                                   it.c0 == 0.0f && it.c1 == 0.0f);
+    if (pure_translation) {
+        const SrAxisTap ax = sr_axis_tap<LOG2F>(col_ok ? cx : 0, it.a2, W, f, ph0, ph1);
+        const int c0 = max(ax.l0, 0), c1 = max(ax.l1, 0);
+        const bool ok0 = ax.l0 >= 0, ok1 = ax.l1 >= 0;
+        const SrAxisTap ayv = sr_axis_tap<LOG2F>(min(cy0 + lane, H - 1), it.b2, H, f, ph0, ph1);   // lane j: row cy0 + j
+        auto xblend = [&](int L) -> float {                         // L >= 0, wave-uniform
+            const float* row = r + L * lw;
+            const float a = (two_lambda_df * row[c0]) * 0.25f, b = (two_lambda_df * row[c1]) * 0.25f;
+            return ax.wl * (ok0 ? a : 0.0f) + ax.wh * (ok1 ? b : 0.0f);
+        };
+        int la = -1, lb = -1;          // cached LR rows (lb the more recent)
+        float va = 0.0f, vb = 0.0f;
+        auto h_of = [&](int L) -> float {
+            if (L < 0) return 0.0f;
+            if (L == lb) return vb;
+            if (L == la) return va;
+            la = lb; va = vb;
+            lb = L; vb = xblend(L);
+            return vb;
+        };
+        const int rows = min(kGrRows, H - cy0);
+        for (int j = 0; j < rows; ++j) {
+            const float wl = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ayv.wl), j));
+            const float wh = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ayv.wh), j));
+            const int l0 = __builtin_amdgcn_readlane(ayv.l0, j), l1 = __builtin_amdgcn_readlane(ayv.l1, j);
+            const float h0 = h_of(l0), h1 = h_of(l1);
+            if (col_ok) out[(cy0 + j) * WP + cx] = wl * h0 + wh * h1;
+        }
+    } else {   // generic projective inverse transforms (never produced by the reference's translate)
+        auto gt_at = [&](int ly, int lx) -> float {
+            const bool ok = (ly >= 0) & (lx >= 0);
+            const float v = (two_lambda_df * r[ok ? ly * lw + lx : 0]) * 0.25f;
+            return ok ? v : 0.0f;
+        };
+        auto rd_gt = [&](int yt, int xt) -> float {
+            return gt_at(sr_gt_index<LOG2F>(yt, H, f, ph0, ph1), sr_gt_index<LOG2F>(xt, W, f, ph0, ph1));
+        };
+        for (int j = 0; j < kGrRows; ++j) {
+            const int cy = cy0 + j;
+            if (cy < H && col_ok) out[cy * WP + cx] = asr_tf_sample(it, rd_gt, cx, cy);
+        }
+    }
+}
+
+template <int LOG2F>
+__global__ __launch_bounds__(256) void sr_backward_adam_kernel(
+    const float* __restrict__ x, float* __restrict__ x_new, const float* __restrict__ resid,
+    const float* __restrict__ inv_rot_tf, const float* __restrict__ inv_trans_tf,
+    float* __restrict__ m, float* __restrict__ v, float* __restrict__ vhat,
+    const float* __restrict__ alphas /* [batch] for this iteration */, float* __restrict__ grad_out,
+    SrDims d, float two_lambda_df, float lambda_tv, float two_lambda_l2, float lambda_l1, SrStep st) {
+    extern __shared__ float contrib[];                     // [n][kBwdPix]
+    const int X = blockIdx.x * kBwdPixX + threadIdx.x;
+    const int Y = blockIdx.y * kBwdPixY + threadIdx.y;
+    const int b = blockIdx.z;
+    const int grp = threadIdx.z;                           // copy group == wave index
+    const int pix = threadIdx.y * kBwdPixX + threadIdx.x;
+    const bool in_image = (X < d.W) & (Y < d.H);
+    const int H = d.H, W = d.W, f = d.f, lw = d.w, lh = d.h;
+    const int ph0 = f / 2 - 1, ph1 = f / 2;
+
+    // Two copies per trip: two independent instruction streams for the compiler to interleave (and to pair in packed
+    // f32 math where it can) in a loop that is bound by VALU issue, not by memory.
+    auto contribution = [&](int n) -> float {
+        float g_df = 0.0f;
+        const int bn = b * d.n + n;
+        const AsrTf8 ir = asr_load_tf(inv_rot_tf + (int64_t)bn * 8);
+        const float* r = resid + (int64_t)bn * lh * lw;
+        const AsrTf8 it = asr_load_tf(inv_trans_tf + (int64_t)bn * 8);
+        auto gt_at = [&](int ly, int lx) -> float {   // branch-free: clamped index, unconditional load, select
+            const bool ok = (ly >= 0) & (lx >= 0);
+            const float v = (two_lambda_df * r[ok ? ly * lw + lx : 0]) * 0.25f;
+            return ok ? v : 0.0f;
+        };
+        const bool pure_translation = (it.a0 == 1.0f && it.a1 == 0.0f && it.b0 == 0.0f && it.b1 == 1.0f &&
+                                       it.c0 == 0.0f && it.c1 == 0.0f);
+        if (pure_translation) {
+            // rotation stage (generic affine), then the separable translate stage
+            float ix, iy;
+            asr_tf_map(ir, (float)X, (float)Y, ix, iy);
+            const float xf = floorf(ix), yf = floorf(iy);
+            const int x0 = asr_coord_to_int(xf), y0 = asr_coord_to_int(yf);
+            const SrAxisTap ax0 = sr_axis_tap<LOG2F>(x0, it.a2, W, f, ph0, ph1);
+            const SrAxisTap ax1 = sr_axis_tap<LOG2F>(x0 + 1, it.a2, W, f, ph0, ph1);
+            const SrAxisTap ay0 = sr_axis_tap<LOG2F>(y0, it.b2, H, f, ph0, ph1);
+            const SrAxisTap ay1 = sr_axis_tap<LOG2F>(y0 + 1, it.b2, H, f, ph0, ph1);
+            // The 4 x 4 G_T taps under this pixel sit on 3 consecutive HR positions per axis, i.e. on at most
+            // 2 x 2 distinct LR residual cells: load those four values once and let every tap select its own
+            // (16 gathers -> 4; the texture-address path, not the VALU, bounded this kernel).
+            const int big = 0x3fffffff;
+            auto lo_of = [&](int a, int b2, int c, int e) {
+                return min(min(a >= 0 ? a : big, b2 >= 0 ? b2 : big), min(c >= 0 ? c : big, e >= 0 ? e : big));
+            };
+            const int cxa = lo_of(ax0.l0, ax0.l1, ax1.l0, ax1.l1), cxb = max(max(ax0.l0, ax0.l1), max(ax1.l0, ax1.l1));
+            const int cya = lo_of(ay0.l0, ay0.l1, ay1.l0, ay1.l1), cyb = max(max(ay0.l0, ay0.l1), max(ay1.l0, ay1.l1));
+            auto in2 = [](int l, int a, int b2) { return (l < 0) | (l == a) | (l == b2); };
+            const bool two_cells = in2(ax0.l0, cxa, cxb) & in2(ax0.l1, cxa, cxb) & in2(ax1.l0, cxa, cxb) & in2(ax1.l1, cxa, cxb) &
+                                   in2(ay0.l0, cya, cyb) & in2(ay0.l1, cya, cyb) & in2(ay1.l0, cya, cyb) & in2(ay1.l1, cya, cyb);
+            const float wxl = (xf + 1.0f) - ix, wxh = ix - xf;
+            if (two_cells) {
+                const int xa = (cxa == big) ? 0 : cxa, xb = max(cxb, 0), ya = (cya == big) ? 0 : cya, yb = max(cyb, 0);
+                const float saa = (two_lambda_df * r[ya * lw + xa]) * 0.25f, sab = (two_lambda_df * r[ya * lw + xb]) * 0.25f;
+                const float sba = (two_lambda_df * r[yb * lw + xa]) * 0.25f, sbb = (two_lambda_df * r[yb * lw + xb]) * 0.25f;
+                // The 16 taps select among the four cell values; selection and the x blend commute with the row choice,
+                // so the x blend is done ONCE per (tap column pair, cell row) and the taps only pick a row afterwards --
+                // the same products and sums on the same operands as tap-by-tap selection (an invalid tap contributes
+                // w * 0 = +0 either way), a third of the v_cndmask / compare instructions this VALU-bound loop spent.
+                auto cell = [&](int lx, float va, float vb) -> float {           // value of column lx in one cell row
+                    const float v = (lx == cxa) ? va : vb;
+                    return (lx >= 0) ? v : 0.0f;
+                };
+                auto hx = [&](const SrAxisTap& ax, float va, float vb) -> float {   // x blend of a tap column pair in one cell row
+                    return ax.wl * cell(ax.l0, va, vb) + ax.wh * cell(ax.l1, va, vb);
+                };
+                const float h0a = hx(ax0, saa, sab), h0b = hx(ax0, sba, sbb);
+                const float h1a = hx(ax1, saa, sab), h1b = hx(ax1, sba, sbb);
+                auto row = [&](int ly, float ha, float hb) -> float {              // the x-blended value of tap row ly
+                    const float v = (ly == cya) ? ha : hb;
+                    return (ly >= 0) ? v : 0.0f;
+                };
+                auto gr = [&](const SrAxisTap& ay, const SrAxisTap& ax, float ha, float hb) -> float {   // G_R at one integer position
+                    const float v = ay.wl * row(ay.l0, ha, hb) + ay.wh * row(ay.l1, ha, hb);
+                    return (ay.inb & ax.inb) ? v : 0.0f;
+                };
+                const float vyf = wxl * gr(ay0, ax0, h0a, h0b) + wxh * gr(ay0, ax1, h1a, h1b);
+                const float vyc = wxl * gr(ay1, ax0, h0a, h0b) + wxh * gr(ay1, ax1, h1a, h1b);
+                g_df += ((yf + 1.0f) - iy) * vyf + (iy - yf) * vyc;
+            } else {   // > 2 distinct cells on an axis: only through float rounding at a binade edge; 16 direct gathers
+                auto gr = [&](const SrAxisTap& ay, const SrAxisTap& ax) -> float {
+                    const float vyf = ax.wl * gt_at(ay.l0, ax.l0) + ax.wh * gt_at(ay.l0, ax.l1);
+                    const float vyc = ax.wl * gt_at(ay.l1, ax.l0) + ax.wh * gt_at(ay.l1, ax.l1);
+                    const float v = ay.wl * vyf + ay.wh * vyc;
+                    return (ay.inb & ax.inb) ? v : 0.0f;
+                };
+                const float vyf = wxl * gr(ay0, ax0) + wxh * gr(ay0, ax1);
+                const float vyc = wxl * gr(ay1, ax0) + wxh * gr(ay1, ax1);
+                g_df += ((yf + 1.0f) - iy) * vyf + (iy - yf) * vyc;
+            }
+        } else {
+            // generic projective inverse transforms (never produced by the reference's translate)
+            auto rd_gt = [&](int yt, int xt) -> float {
+                return gt_at(sr_gt_index<LOG2F>(yt, H, f, ph0, ph1), sr_gt_index<LOG2F>(xt, W, f, ph0, ph1));
+            };
+            auto rd_gr = [&](int yr, int xr) -> float {
+                if (!(yr >= 0 && yr < H && xr >= 0 && xr < W)) return 0.0f;
+                return asr_tf_sample(it, rd_gt, xr, yr);
+            };
+            g_df += asr_tf_sample(ir, rd_gr, X, Y);
+        }
+        return g_df;
+    };
+    int n = grp;
+    for (; n + kBwdSplit < d.n; n += 2 * kBwdSplit) {
+        const float g0 = contribution(n), g1 = contribution(n + kBwdSplit);
+        contrib[n * kBwdPix + pix] = g0;
+        contrib[(n + kBwdSplit) * kBwdPix + pix] = g1;
+    }
+    if (n < d.n) contrib[n * kBwdPix + pix] = contribution(n);
+    __syncthreads();
+    if (grp != 0 || !in_image) return;
+    float g_df = 0.0f;
+    for (int n = 0; n < d.n; ++n) g_df += contrib[n * kBwdPix + pix];   // fixed order n = 0..N-1
+
+    sr_prior_and_update(x, x_new, m, v, vhat, alphas, grad_out, d, b, X, Y, g_df, lambda_tv, two_lambda_l2, lambda_l1, st);
+}
+
+// Backward, gather form: one thread per HR pixel walks the copies in order (the oracle's summation order) and takes
+// the rotation's 2 x 2 taps of copy n from the zero-bordered G_R plane: two unaligned 8-byte loads, no bounds tests.
+// The copy index is uniform, so the transforms are scalar loads; the loop is unrolled so the taps of several copies are
+// in flight under the dependent chain of adds.
+typedef float asr_f2u __attribute__((ext_vector_type(2), aligned(4)));
+
+__global__ __launch_bounds__(256) void sr_backward_gather_kernel(
+    const float* __restrict__ x, float* __restrict__ x_new, const float* __restrict__ gr_planes,
+    const float* __restrict__ inv_rot_tf, float* __restrict__ m, float* __restrict__ v, float* __restrict__ vhat,
+    const float* __restrict__ alphas, float* __restrict__ grad_out, SrDims d, float lambda_tv, float two_lambda_l2,
+    float lambda_l1, SrStep st) {
+    const int X = blockIdx.x * 64 + threadIdx.x;
+    const int Y = blockIdx.y * 4 + threadIdx.y;
+    const int b = blockIdx.z;
+    const int H = d.H, W = d.W, WP = W + 2 * kGrPadX;
+    if (X >= W || Y >= H) return;
+    const size_t plane = sr_gr_plane_elems(H, W);
+    const float* const g0 = gr_planes + (size_t)b * d.n * plane + (size_t)kGrPadY * WP + kGrPadX;
+    const float fx = (float)X, fy = (float)Y;
+    float g_df = 0.0f;
+#pragma unroll 4
+    for (int n = 0; n < d.n; ++n) {
+        const AsrTf8 ir = asr_load_tf(inv_rot_tf + ((int64_t)b * d.n + n) * 8);
+        float ix, iy;
+        float c = 0.0f;
+        if (asr_tf_map(ir, fx, fy, ix, iy)) {
+            const float xf = floorf(ix), yf = floorf(iy);
+            const int x0 = min(max(asr_coord_to_int(xf), -2), W), y0 = min(max(asr_coord_to_int(yf), -2), H);
+            const float* p = g0 + (size_t)n * plane + y0 * WP + x0;
+            const asr_f2u top = *reinterpret_cast<const asr_f2u*>(p);
+            const asr_f2u bot = *reinterpret_cast<const asr_f2u*>(p + WP);
+            const float wxl = (xf + 1.0f) - ix, wxh = ix - xf;
+            const float vyf = wxl * top.x + wxh * top.y;
+            const float vyc = wxl * bot.x + wxh * bot.y;
+            c = ((yf + 1.0f) - iy) * vyf + (iy - yf) * vyc;
+        }
+        g_df += c;
+    }
+    sr_prior_and_update(x, x_new, m, v, vhat, alphas, grad_out, d, b, X, Y, g_df, lambda_tv, two_lambda_l2, lambda_l1, st);
+}
+
 typedef void (*SrBwdKernel)(const float*, float*, const float*, const float*, const float*, float*, float*, float*,
                             const float*, float*, SrDims, float, float, float, float, SrStep);
 
@@ -387,6 +518,16 @@ SrBwdKernel sr_backward_kernel_for(int f) {
         case 4: return sr_backward_adam_kernel<2>;
         case 8: return sr_backward_adam_kernel<3>;
         default: return sr_backward_adam_kernel<0>;   // any other even factor: integer division
+    }
+}
+
+typedef void (*SrGradTranslateKernel)(const float*, const float*, float*, SrDims, float);
+SrGradTranslateKernel sr_grad_translate_kernel_for(int f) {
+    switch (f) {
+        case 2: return sr_grad_translate_kernel<1>;
+        case 4: return sr_grad_translate_kernel<2>;
+        case 8: return sr_grad_translate_kernel<3>;
+        default: return sr_grad_translate_kernel<0>;
     }
 }
 
@@ -547,6 +688,12 @@ int prepare_backward(const SrDims& d) {
     }
     return ASR_OK;
 }
+dim3 gr_grid(const SrDims& d) {
+    return dim3((unsigned)asr_cdiv(d.W, 64), (unsigned)asr_cdiv(d.H, 4 * kGrRows), (unsigned)(d.batch * d.n));
+}
+dim3 gather_grid(const SrDims& d) {
+    return dim3((unsigned)asr_cdiv(d.W, 64), (unsigned)asr_cdiv(d.H, 4), (unsigned)d.batch);
+}
 dim3 bwd_grid(const SrDims& d) { return dim3((unsigned)asr_cdiv(d.W, kBwdPixX), (unsigned)asr_cdiv(d.H, kBwdPixY), (unsigned)d.batch); }
 const dim3 kBwdBlock(kBwdPixX, kBwdPixY, kBwdSplit);
 size_t bwd_lds(const SrDims& d) { return sizeof(float) * (size_t)d.n * kBwdPix; }
@@ -678,7 +825,8 @@ extern "C" int asr_sr_loss_terms_f64(const float* x, const float* resid, double*
 }
 
 extern "C" size_t asr_sr_solve_workspace_bytes(int batch, int n, int H, int W, int h, int w) {
-    return sizeof(float) * ((size_t)batch * n * h * w + (size_t)batch * H * W);
+    // residuals [batch*n, h, w] + the ping-pong x [batch, H, W] + the zero-bordered G_R planes [batch*n, H + 4, W + 8]
+    return sizeof(float) * ((size_t)batch * n * h * w + (size_t)batch * H * W + (size_t)batch * n * sr_gr_plane_elems(H, W));
 }
 
 // The whole optimisation loop of augmented_superresolution (superresolution.py:120-135) as one
@@ -711,9 +859,15 @@ extern "C" int asr_sr_solve_cfg_f32(float* x, const float* y, const float* rot_t
     float* x_alt = resid + (size_t)batch * n * h * w;
     float* cur = x;
     float* nxt = x_alt;
+    // ASR_SR_FUSED_BWD=1: the one-kernel backward (what asr_sr_backward_* runs, which has no workspace) -- A/B timing
+    static const bool fused = getenv("ASR_SR_FUSED_BWD") && atoi(getenv("ASR_SR_FUSED_BWD")) != 0;
     rc = prepare_backward(d);
     if (rc != ASR_OK) return rc;
+    float* const gr = x_alt + (size_t)batch * H * W;
     const SrBwdKernel bwd_kernel = sr_backward_kernel_for(d.f);
+    const SrGradTranslateKernel gr_kernel = sr_grad_translate_kernel_for(d.f);
+    if (!fused && num_iter > 0)   // the planes' borders stay zero for the whole solve; the interiors are rewritten every iteration
+        ASR_HIP_CHECK(hipMemsetAsync(gr, 0, sizeof(float) * (size_t)batch * n * sr_gr_plane_elems(H, W), s));
     for (int it = 0; it < num_iter; ++it) {
         hipLaunchKernelGGL(sr_forward_residual_kernel, lr_grid(d), kBlock, 0, s, cur, y, rot_tf, trans_tf, resid, d);
         ASR_LAUNCH_CHECK();
@@ -721,9 +875,16 @@ extern "C" int asr_sr_solve_cfg_f32(float* x, const float* y, const float* rot_t
             rc = asr_sr_loss_terms_cfg_f64(cur, resid, last_loss_terms, batch, n, H, W, h, w, cfg, stream);
             if (rc != ASR_OK) return rc;
         }
-        hipLaunchKernelGGL(bwd_kernel, bwd_grid(d), kBwdBlock, bwd_lds(d), s, cur, nxt, resid, inv_rot_tf, inv_trans_tf,
-                           m, v, vhat, alphas + (size_t)it * batch, (float*)nullptr, d, 2.0f * lambda_df, lambda_tv,
-                           2.0f * lambda_l2, lambda_l1, st);
+        if (!fused) {
+            hipLaunchKernelGGL(gr_kernel, gr_grid(d), dim3(64, 4), 0, s, resid, inv_trans_tf, gr, d, 2.0f * lambda_df);
+            ASR_LAUNCH_CHECK();
+            hipLaunchKernelGGL(sr_backward_gather_kernel, gather_grid(d), dim3(64, 4), 0, s, cur, nxt, gr, inv_rot_tf, m, v, vhat,
+                               alphas + (size_t)it * batch, (float*)nullptr, d, lambda_tv, 2.0f * lambda_l2, lambda_l1, st);
+        } else {
+            hipLaunchKernelGGL(bwd_kernel, bwd_grid(d), kBwdBlock, bwd_lds(d), s, cur, nxt, resid, inv_rot_tf, inv_trans_tf,
+                               m, v, vhat, alphas + (size_t)it * batch, (float*)nullptr, d, 2.0f * lambda_df, lambda_tv,
+                               2.0f * lambda_l2, lambda_l1, st);
+        }
         ASR_LAUNCH_CHECK();
         float* t = cur; cur = nxt; nxt = t;
     }

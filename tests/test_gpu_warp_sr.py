@@ -223,3 +223,31 @@ def test_opm_modes_match_oracle(dev):
     assert np.array_equal(g_m.cpu().numpy(), np.stack(mm)[..., 0])
     cm, _ = o_aug.opm(logits, 8, "slice")
     np.testing.assert_allclose(ops.opm_slice(ld, 8).cpu().numpy(), np.stack(cm)[..., 0], rtol=0, atol=1e-7)
+
+
+@pytest.mark.parametrize("H,h", [(128, 32), (64, 32), (128, 16), (96, 16)])
+def test_sr_solve_two_kernel_backward_is_bit_identical_to_fused(dev, H, h):
+    """asr_sr_solve_* evaluates the translate stage of the gradient once per (copy, HR position) into a plane and gathers
+    the rotation taps from it; asr_sr_backward_* (no workspace) nests the two stages in one kernel.  Same arithmetic ->
+    the solver's x after k iterations equals k explicit forward + fused-backward steps bit for bit (f = 4, 2, 8, 6)."""
+    from asr_amd import ops, transforms as T
+    n, b, iters = 7, 2, 4
+    y, angs, shs = _sr_problem(11, b, n, H, h)
+    lam = (1.0, 0.3, 0.7, 0.0)
+    rot, tr, irot, itr = _dev_tfs(angs, shs, H)
+    yd = ops.to_device(y)
+    b1, b2, eps = np.float32(0.9), np.float32(0.999), np.float32(1e-7)
+    alphas = np.zeros((iters, b), np.float32)
+    for it in range(iters):
+        alphas[it, :] = T.adam_alpha(np.float32(1e-3), b1, b2, it + 1)
+    x_solve, _ = ops.sr_solve(ops.sr_init_target(yd, (H, H)), yd, rot, tr, irot, itr, ops.to_device(alphas), lam,
+                              np.float32(1) - b1, np.float32(1) - b2, eps, True, want_loss=False)
+    xd = ops.sr_init_target(yd, (H, H))
+    m = torch.zeros_like(xd); v = torch.zeros_like(xd); vh = torch.zeros_like(xd)
+    for it in range(iters):
+        resid = ops.sr_forward_residual(xd, yd, rot, tr)
+        xd, _ = ops.sr_backward_adam(xd, resid, irot, itr, lam,
+                                     adam=dict(m=m, v=v, vhat=vh, alphas=ops.to_device(alphas[it]),
+                                               one_minus_beta1=np.float32(1) - b1, one_minus_beta2=np.float32(1) - b2,
+                                               epsilon=eps, amsgrad=True))
+    assert torch.equal(x_solve, xd)
