@@ -42,8 +42,41 @@ __global__ __launch_bounds__(256) void sr_init_kernel(const float* __restrict__ 
     x[((int64_t)b * d.H + Y) * d.W + X] = top + (bot - top) * ly.t;
 }
 
+// ---- zero-bordered planes ---------------------------------------------------------------------------
+// The solver keeps the images its bilinear gathers sample (the current x for K_fwd, the per-copy gradient planes G_R for
+// the backward gather) with a zero border: row stride W + 8 (4 zero columns each side), 2 zero rows above and below.  A
+// 2 x 2 tap block whose floor coordinate is clamped to [-2, W] x [-2, H] then reads zeros exactly where the unclamped
+// taps fall outside the image (TF's CONSTANT-0 fill), so a sample is two unaligned 8-byte loads with no per-tap bounds
+// test and no select; the weights still come from the unclamped coordinate.  Same products and sums as
+// asr_tf_bilinear over a bounds-checked reader -> bit-identical.
+constexpr int kGrPadX = 4, kGrPadY = 2;
+__host__ __device__ inline size_t sr_gr_plane_elems(int H, int W) { return (size_t)(H + 2 * kGrPadY) * (size_t)(W + 2 * kGrPadX); }
+typedef float asr_f2u __attribute__((ext_vector_type(2), aligned(4)));
+
+// plane = first element of the bordered plane (its top-left border corner), WP = W + 2 * kGrPadX.  The element offset is
+// non-negative, so the loads take the scalar plane base + a 32-bit lane offset.
+__device__ __forceinline__ float sr_bilinear_bordered(const float* __restrict__ plane, int WP, int H, int W, float ix, float iy) {
+    const float xf = floorf(ix), yf = floorf(iy);
+    const int x0 = min(max(asr_coord_to_int(xf), -2), W), y0 = min(max(asr_coord_to_int(yf), -2), H);
+    const unsigned off = (unsigned)((y0 + kGrPadY) * WP + (x0 + kGrPadX));
+    const asr_f2u top = *reinterpret_cast<const asr_f2u*>(plane + off);
+    const asr_f2u bot = *reinterpret_cast<const asr_f2u*>(plane + (off + (unsigned)WP));
+    const float wxl = (xf + 1.0f) - ix, wxh = ix - xf;
+    const float vyf = wxl * top.x + wxh * top.y;
+    const float vyc = wxl * bot.x + wxh * bot.y;
+    return ((yf + 1.0f) - iy) * vyf + (iy - yf) * vyc;
+}
+
+// asr_tf_map for a transform known to be affine (c0 == c1 == 0): the same two expressions without the (uniform) branch
+// on the projective terms -- a branch inside a sampling loop makes the compiler wait for each sample's loads in turn.
+__device__ __forceinline__ void sr_map_affine(const AsrTf8& t, float x, float y, float& ix, float& iy) {
+    ix = t.a0 * x + t.a1 * y + t.a2;
+    iy = t.b0 * x + t.b1 * y + t.b2;
+}
+
 // ---- K_fwd --------------------------------------------------------------------------------
-// One thread per LR residual element (b, n, i, j).
+// One thread per LR residual element (b, n, i, j).  BORDERED: x is the solver's zero-bordered copy [batch, H+4, W+8].
+template <bool BORDERED>
 __global__ __launch_bounds__(256) void sr_forward_residual_kernel(
     const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ rot_tf,
     const float* __restrict__ trans_tf, float* __restrict__ resid, SrDims d) {
@@ -52,10 +85,10 @@ __global__ __launch_bounds__(256) void sr_forward_residual_kernel(
     const int bn = blockIdx.z;  // b * n + copy
     if (j >= d.w || i >= d.h) return;
     const int b = bn / d.n;
-    const float* img = x + (int64_t)b * d.H * d.W;
+    const int H = d.H, W = d.W, WP = W + 2 * kGrPadX;
+    const float* img = BORDERED ? x + (size_t)b * sr_gr_plane_elems(H, W) : x + (int64_t)b * H * W;
     const AsrTf8 tr = asr_load_tf(rot_tf + (int64_t)bn * 8);
     const AsrTf8 tt = asr_load_tf(trans_tf + (int64_t)bn * 8);
-    const int H = d.H, W = d.W;
 
     // Branch-free taps: clamp the index, load unconditionally, select afterwards -- the 64 image taps of one
     // residual element are then issued back to back instead of one exec-masked branch + wait each.
@@ -66,7 +99,13 @@ __global__ __launch_bounds__(256) void sr_forward_residual_kernel(
     };
     auto rd_rot = [&](int yr, int xr) -> float {
         const bool ok = (yr >= 0) & (yr < H) & (xr >= 0) & (xr < W);
-        const float v = asr_tf_sample(tr, rd_x, xr, yr);
+        float v;
+        if (BORDERED) {
+            float ix, iy;
+            v = asr_tf_map(tr, (float)xr, (float)yr, ix, iy) ? sr_bilinear_bordered(img, WP, H, W, ix, iy) : 0.0f;
+        } else {
+            v = asr_tf_sample(tr, rd_x, xr, yr);
+        }
         return ok ? v : 0.0f;
     };
     auto T = [&](int yt, int xt) -> float { return asr_tf_sample(tt, rd_rot, xt, yt); };
@@ -85,12 +124,26 @@ __global__ __launch_bounds__(256) void sr_forward_residual_kernel(
     const float fx0 = floorf(jx0), fx1 = floorf(jx1), fy0 = floorf(jy0), fy1 = floorf(jy1);
     const int cx0 = asr_coord_to_int(fx0), cx1 = asr_coord_to_int(fx1);
     const int cy0 = asr_coord_to_int(fy0), cy1 = asr_coord_to_int(fy1);
+    const bool rot_affine = (tr.c0 == 0.0f) & (tr.c1 == 0.0f);
     if (pure_translation && cx1 == cx0 + 1 && cy1 == cy0 + 1) {
         float rv[3][3];
+        if (BORDERED && rot_affine) {   // no branch inside: the 18 loads of the 9 samples go out together
 #pragma unroll
-        for (int a = 0; a < 3; ++a)
+            for (int a = 0; a < 3; ++a)
 #pragma unroll
-            for (int c = 0; c < 3; ++c) rv[a][c] = rd_rot(cy0 + a, cx0 + c);
+                for (int c = 0; c < 3; ++c) {
+                    const int yr = cy0 + a, xr = cx0 + c;
+                    float ix, iy;
+                    sr_map_affine(tr, (float)xr, (float)yr, ix, iy);
+                    const float v = sr_bilinear_bordered(img, WP, H, W, ix, iy);
+                    rv[a][c] = ((yr >= 0) & (yr < H) & (xr >= 0) & (xr < W)) ? v : 0.0f;
+                }
+        } else {
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) rv[a][c] = rd_rot(cy0 + a, cx0 + c);
+        }
         const float wxl0 = (fx0 + 1.0f) - jx0, wxh0 = jx0 - fx0, wxl1 = (fx1 + 1.0f) - jx1, wxh1 = jx1 - fx1;
         const float wyl0 = (fy0 + 1.0f) - jy0, wyh0 = jy0 - fy0, wyl1 = (fy1 + 1.0f) - jy1, wyh1 = jy1 - fy1;
         auto Tq = [&](int a, int c, float wxl, float wxh, float wyl, float wyh) -> float {
@@ -160,7 +213,8 @@ __device__ __forceinline__ void sr_prior_and_update(const float* __restrict__ x,
                                                     float* __restrict__ v, float* __restrict__ vhat,
                                                     const float* __restrict__ alphas, float* __restrict__ grad_out,
                                                     const SrDims& d, int b, int X, int Y, float g_df, float lambda_tv,
-                                                    float two_lambda_l2, float lambda_l1, const SrStep& st) {
+                                                    float two_lambda_l2, float lambda_l1, const SrStep& st,
+                                                    float* __restrict__ x_bordered_out = nullptr) {
     const int H = d.H, W = d.W;
     // priors (superresolution.py:81-98): TV (forward differences, last row/col 0) or bilateral TV, L2, L1
     const float* img = x + (int64_t)b * H * W;
@@ -205,21 +259,22 @@ __device__ __forceinline__ void sr_prior_and_update(const float* __restrict__ x,
     // apply_gradients: the dense CPU kernels of tensorflow/core/kernels/training_ops.cc that Keras 2.7 dispatches to
     // (operation order as in their Eigen expressions; alpha = the per-step scalar the host prepared)
     const float alpha = alphas[b];
+    float xn;
     switch (st.optimizer) {
         case ASR_OPT_SGD: {                                 // ApplyGradientDescent / ApplyKerasMomentum
             if (st.c0 == 0.0f) {
-                x_new[o] = xc - g * alpha;
+                xn = xc - g * alpha;
             } else {
                 const float acc = m[o] * st.c0 - g * alpha;
                 m[o] = acc;
-                x_new[o] = st.flag ? xc + (acc * st.c0 - g * alpha) : xc + acc;
+                xn = st.flag ? xc + (acc * st.c0 - g * alpha) : xc + acc;
             }
             break;
         }
         case ASR_OPT_ADAGRAD: {                             // ApplyAdagradV2
             const float acc = v[o] + g * g;
             v[o] = acc;
-            x_new[o] = xc - (g * alpha) / (sqrtf(acc) + st.c2);
+            xn = xc - (g * alpha) / (sqrtf(acc) + st.c2);
             break;
         }
         case ASR_OPT_ADADELTA: {                            // ApplyAdadelta: c0 = rho, c1 = 1 - rho
@@ -227,7 +282,7 @@ __device__ __forceinline__ void sr_prior_and_update(const float* __restrict__ x,
             v[o] = acc;
             const float au = m[o];
             const float upd = sqrtf(au + st.c2) * (1.0f / sqrtf(acc + st.c2)) * g;
-            x_new[o] = xc - upd * alpha;
+            xn = xc - upd * alpha;
             m[o] = au * st.c0 + (upd * upd) * st.c1;
             break;
         }
@@ -237,7 +292,7 @@ __device__ __forceinline__ void sr_prior_and_update(const float* __restrict__ x,
             const float vv = fmaxf(st.c1 * v[o], fabsf(g));
             m[o] = mm;
             v[o] = vv;
-            x_new[o] = xc - alpha * (mm / (vv + st.c2));
+            xn = xc - alpha * (mm / (vv + st.c2));
             break;
         }
         default: {                                          // ApplyAdam[WithAmsgrad]: c0 = 1 - beta1, c1 = 1 - beta2
@@ -254,9 +309,12 @@ __device__ __forceinline__ void sr_prior_and_update(const float* __restrict__ x,
             } else {
                 denom = sqrtf(vv) + st.c2;
             }
-            x_new[o] = xc - (mm * alpha) / denom;
+            xn = xc - (mm * alpha) / denom;
         }
     }
+    x_new[o] = xn;
+    if (x_bordered_out)   // the solver's zero-bordered copy for the next K_fwd
+        x_bordered_out[(size_t)b * sr_gr_plane_elems(H, W) + (size_t)(Y + kGrPadY) * (W + 2 * kGrPadX) + (X + kGrPadX)] = xn;
 }
 
 // Work split: a workgroup owns 64 HR pixels (32 x 2) and NSPLIT = 4 waves; wave g evaluates the copies
@@ -277,9 +335,7 @@ constexpr int kBwdSplit = 4, kBwdPixX = 32, kBwdPixY = 2, kBwdPix = kBwdPixX * k
 //   Plane geometry: row stride W + 8 (4 zero columns each side), 2 zero rows above and below.  A tap pair whose floor
 //   coordinate is clamped to [-2, W] x [-2, H] reads only zeros wherever the unclamped taps are out of the image, so the
 //   gather needs no per-tap bounds test and no select.
-constexpr int kGrPadX = 4, kGrPadY = 2;
 constexpr int kGrRows = 16;   // HR rows per wave of sr_grad_translate_kernel
-__host__ __device__ inline size_t sr_gr_plane_elems(int H, int W) { return (size_t)(H + 2 * kGrPadY) * (size_t)(W + 2 * kGrPadX); }
 
 // One wave: 64 columns x kGrRows rows of one copy.  The x taps are per lane (its column); the y taps of the wave's rows
 // are computed by lanes 0..kGrRows-1 in ONE pass and fetched per row with v_readlane (they are wave-uniform: scalar row
@@ -470,43 +526,60 @@ __global__ __launch_bounds__(256) void sr_backward_adam_kernel(
 
 // Backward, gather form: one thread per HR pixel walks the copies in order (the oracle's summation order) and takes
 // the rotation's 2 x 2 taps of copy n from the zero-bordered G_R plane: two unaligned 8-byte loads, no bounds tests.
-// The copy index is uniform, so the transforms are scalar loads; the loop is unrolled so the taps of several copies are
-// in flight under the dependent chain of adds.
-typedef float asr_f2u __attribute__((ext_vector_type(2), aligned(4)));
+// The copy index is uniform, so the transforms are scalar loads.  The copies are taken K at a time: when all K rotations
+// are affine (always, for the reference) the chunk is branch-free, so its 2K loads are in flight together and only the
+// final adds are a dependent chain.
+template <int K>
+__device__ __forceinline__ float sr_gather_chunk(float g_df, const float* __restrict__ inv_rot_tf, const float* __restrict__ planes,
+                                                 size_t plane, int WP, int H, int W, float fx, float fy) {
+    AsrTf8 t[K];
+    bool affine = true;
+#pragma unroll
+    for (int u = 0; u < K; ++u) {
+        t[u] = asr_load_tf(inv_rot_tf + u * 8);
+        affine &= (t[u].c0 == 0.0f) & (t[u].c1 == 0.0f);
+    }
+    float c[K];
+    if (affine) {
+#pragma unroll
+        for (int u = 0; u < K; ++u) {
+            float ix, iy;
+            sr_map_affine(t[u], fx, fy, ix, iy);
+            c[u] = sr_bilinear_bordered(planes + u * plane, WP, H, W, ix, iy);
+        }
+    } else {
+#pragma unroll
+        for (int u = 0; u < K; ++u) {
+            float ix, iy;
+            c[u] = asr_tf_map(t[u], fx, fy, ix, iy) ? sr_bilinear_bordered(planes + u * plane, WP, H, W, ix, iy) : 0.0f;
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < K; ++u) g_df += c[u];
+    return g_df;
+}
 
 __global__ __launch_bounds__(256) void sr_backward_gather_kernel(
     const float* __restrict__ x, float* __restrict__ x_new, const float* __restrict__ gr_planes,
     const float* __restrict__ inv_rot_tf, float* __restrict__ m, float* __restrict__ v, float* __restrict__ vhat,
     const float* __restrict__ alphas, float* __restrict__ grad_out, SrDims d, float lambda_tv, float two_lambda_l2,
-    float lambda_l1, SrStep st) {
+    float lambda_l1, SrStep st, float* __restrict__ x_bordered_out) {
     const int X = blockIdx.x * 64 + threadIdx.x;
     const int Y = blockIdx.y * 4 + threadIdx.y;
     const int b = blockIdx.z;
     const int H = d.H, W = d.W, WP = W + 2 * kGrPadX;
     if (X >= W || Y >= H) return;
     const size_t plane = sr_gr_plane_elems(H, W);
-    const float* const g0 = gr_planes + (size_t)b * d.n * plane + (size_t)kGrPadY * WP + kGrPadX;
+    const float* const planes = gr_planes + (size_t)b * d.n * plane;
+    const float* const tfs = inv_rot_tf + (int64_t)b * d.n * 8;
     const float fx = (float)X, fy = (float)Y;
     float g_df = 0.0f;
-#pragma unroll 4
-    for (int n = 0; n < d.n; ++n) {
-        const AsrTf8 ir = asr_load_tf(inv_rot_tf + ((int64_t)b * d.n + n) * 8);
-        float ix, iy;
-        float c = 0.0f;
-        if (asr_tf_map(ir, fx, fy, ix, iy)) {
-            const float xf = floorf(ix), yf = floorf(iy);
-            const int x0 = min(max(asr_coord_to_int(xf), -2), W), y0 = min(max(asr_coord_to_int(yf), -2), H);
-            const float* p = g0 + (size_t)n * plane + y0 * WP + x0;
-            const asr_f2u top = *reinterpret_cast<const asr_f2u*>(p);
-            const asr_f2u bot = *reinterpret_cast<const asr_f2u*>(p + WP);
-            const float wxl = (xf + 1.0f) - ix, wxh = ix - xf;
-            const float vyf = wxl * top.x + wxh * top.y;
-            const float vyc = wxl * bot.x + wxh * bot.y;
-            c = ((yf + 1.0f) - iy) * vyf + (iy - yf) * vyc;
-        }
-        g_df += c;
-    }
-    sr_prior_and_update(x, x_new, m, v, vhat, alphas, grad_out, d, b, X, Y, g_df, lambda_tv, two_lambda_l2, lambda_l1, st);
+    int n = 0;
+    for (; n + 8 <= d.n; n += 8) g_df = sr_gather_chunk<8>(g_df, tfs + n * 8, planes + n * plane, plane, WP, H, W, fx, fy);
+    if (n + 4 <= d.n) { g_df = sr_gather_chunk<4>(g_df, tfs + n * 8, planes + n * plane, plane, WP, H, W, fx, fy); n += 4; }
+    for (; n < d.n; ++n) g_df = sr_gather_chunk<1>(g_df, tfs + n * 8, planes + n * plane, plane, WP, H, W, fx, fy);
+    sr_prior_and_update(x, x_new, m, v, vhat, alphas, grad_out, d, b, X, Y, g_df, lambda_tv, two_lambda_l2, lambda_l1, st,
+                        x_bordered_out);
 }
 
 typedef void (*SrBwdKernel)(const float*, float*, const float*, const float*, const float*, float*, float*, float*,
@@ -722,7 +795,7 @@ extern "C" int asr_sr_forward_residual_f32(const float* x, const float* y, const
     SrDims d;
     int rc = check_dims("asr_sr_forward_residual_f32", batch, n, H, W, h, w, &d);
     if (rc != ASR_OK) return rc;
-    hipLaunchKernelGGL(sr_forward_residual_kernel, lr_grid(d), kBlock, 0, asr_stream(stream), x, y, rot_tf, trans_tf,
+    hipLaunchKernelGGL(sr_forward_residual_kernel<false>, lr_grid(d), kBlock, 0, asr_stream(stream), x, y, rot_tf, trans_tf,
                        resid, d);
     ASR_LAUNCH_CHECK();
     return ASR_OK;
@@ -825,8 +898,8 @@ extern "C" int asr_sr_loss_terms_f64(const float* x, const float* resid, double*
 }
 
 extern "C" size_t asr_sr_solve_workspace_bytes(int batch, int n, int H, int W, int h, int w) {
-    // residuals [batch*n, h, w] + the ping-pong x [batch, H, W] + the zero-bordered G_R planes [batch*n, H + 4, W + 8]
-    return sizeof(float) * ((size_t)batch * n * h * w + (size_t)batch * H * W + (size_t)batch * n * sr_gr_plane_elems(H, W));
+    // residuals [batch*n, h, w] + the ping-pong x [batch, H, W] + the zero-bordered planes [H + 4, W + 8]: G_R per copy, x per image
+    return sizeof(float) * ((size_t)batch * n * h * w + (size_t)batch * H * W + ((size_t)batch * n + batch) * sr_gr_plane_elems(H, W));
 }
 
 // The whole optimisation loop of augmented_superresolution (superresolution.py:120-135) as one
@@ -866,10 +939,19 @@ extern "C" int asr_sr_solve_cfg_f32(float* x, const float* y, const float* rot_t
     float* const gr = x_alt + (size_t)batch * H * W;
     const SrBwdKernel bwd_kernel = sr_backward_kernel_for(d.f);
     const SrGradTranslateKernel gr_kernel = sr_grad_translate_kernel_for(d.f);
-    if (!fused && num_iter > 0)   // the planes' borders stay zero for the whole solve; the interiors are rewritten every iteration
-        ASR_HIP_CHECK(hipMemsetAsync(gr, 0, sizeof(float) * (size_t)batch * n * sr_gr_plane_elems(H, W), s));
+    float* const xb = gr + (size_t)batch * n * sr_gr_plane_elems(H, W);   // bordered copy of the current x
+    if (!fused && num_iter > 0) {   // the borders stay zero for the whole solve; the interiors are rewritten every iteration
+        const size_t pe = sr_gr_plane_elems(H, W);
+        ASR_HIP_CHECK(hipMemsetAsync(gr, 0, sizeof(float) * ((size_t)batch * n + batch) * pe, s));
+        const size_t wp = (size_t)W + 2 * kGrPadX;
+        for (int b = 0; b < batch; ++b)
+            ASR_HIP_CHECK(hipMemcpy2DAsync(xb + b * pe + kGrPadY * wp + kGrPadX, wp * sizeof(float), x + (size_t)b * H * W,
+                                           (size_t)W * sizeof(float), (size_t)W * sizeof(float), (size_t)H,
+                                           hipMemcpyDeviceToDevice, s));
+    }
     for (int it = 0; it < num_iter; ++it) {
-        hipLaunchKernelGGL(sr_forward_residual_kernel, lr_grid(d), kBlock, 0, s, cur, y, rot_tf, trans_tf, resid, d);
+        if (fused) hipLaunchKernelGGL(sr_forward_residual_kernel<false>, lr_grid(d), kBlock, 0, s, cur, y, rot_tf, trans_tf, resid, d);
+        else hipLaunchKernelGGL(sr_forward_residual_kernel<true>, lr_grid(d), kBlock, 0, s, xb, y, rot_tf, trans_tf, resid, d);
         ASR_LAUNCH_CHECK();
         if (last_loss_terms && it == num_iter - 1) {
             rc = asr_sr_loss_terms_cfg_f64(cur, resid, last_loss_terms, batch, n, H, W, h, w, cfg, stream);
@@ -879,7 +961,7 @@ extern "C" int asr_sr_solve_cfg_f32(float* x, const float* y, const float* rot_t
             hipLaunchKernelGGL(gr_kernel, gr_grid(d), dim3(64, 4), 0, s, resid, inv_trans_tf, gr, d, 2.0f * lambda_df);
             ASR_LAUNCH_CHECK();
             hipLaunchKernelGGL(sr_backward_gather_kernel, gather_grid(d), dim3(64, 4), 0, s, cur, nxt, gr, inv_rot_tf, m, v, vhat,
-                               alphas + (size_t)it * batch, (float*)nullptr, d, lambda_tv, 2.0f * lambda_l2, lambda_l1, st);
+                               alphas + (size_t)it * batch, (float*)nullptr, d, lambda_tv, 2.0f * lambda_l2, lambda_l1, st, xb);
         } else {
             hipLaunchKernelGGL(bwd_kernel, bwd_grid(d), kBwdBlock, bwd_lds(d), s, cur, nxt, resid, inv_rot_tf, inv_trans_tf,
                                m, v, vhat, alphas + (size_t)it * batch, (float*)nullptr, d, 2.0f * lambda_df, lambda_tv,

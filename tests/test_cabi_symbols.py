@@ -41,7 +41,7 @@ def test_argument_validation_needs_no_gpu(lib):
     assert rc == -1 and b"null pointer" in lib.asr_last_error()
     rc = lib.asr_pwconv_packed_floats(728, 728)
     assert rc == 736 * 768
-    assert lib.asr_sr_solve_workspace_bytes(2, 3, 8, 8, 4, 4) == 4 * (2 * 3 * 16 + 2 * 64 + 2 * 3 * (8 + 4) * (8 + 8))
+    assert lib.asr_sr_solve_workspace_bytes(2, 3, 8, 8, 4, 4) == 4 * (2 * 3 * 16 + 2 * 64 + (2 * 3 + 2) * (8 + 4) * (8 + 8))
 
 
 def test_product_refuses_cpu_tensors(lib):
