@@ -1,5 +1,6 @@
 // Remaining DeepLabV3+ layers as NHWC float32 kernels (gfx950):
 //   asr_conv3x3_direct_f32   dense 3x3 for tiny Cin (entry_flow_conv1_1: 3 -> 32, stride 2, model.py:150-151)
+//   asr_conv3x3_stem_f16x3   the same layer as a split-f16 MFMA implicit GEMM (precision f16x3)
 //   asr_gap_f32              GlobalAveragePooling2D(keepdims) (model.py:196-197)
 //   asr_resize_bilinear_f32  Resizing(bilinear) = tf.image.resize half-pixel (model.py:109-110,204-205,241-242)
 // All HBM-bound; lanes own 4 consecutive channels so stores are whole 16-byte pieces of a pixel row.
@@ -120,6 +121,88 @@ __global__ __launch_bounds__(256) void conv3x3_stem_kernel(const float* __restri
     }
 }
 
+// ---- entry_flow_conv1_1 on the matrix cores (asr_conv3x3_stem_f16x3) ---------------------------------------------
+// 3 -> 32 channels, 3 x 3: an implicit GEMM with K = 27 (padded to 32), N = 32.  One wave = 32 consecutive output
+// pixels of a row: it gathers its A fragment straight from the image (lane = pixel, 16 of the 32 k slots each, scalar
+// dword loads with clamped addresses + select -- the 27 inputs of a pixel are three 36-byte runs), splits it to
+// hi/lo f16 in registers and issues 2 k-steps x {lo*hi, hi*lo, hi*hi} v_mfma_f32_32x32x16_f16; the weights' B fragments
+// are split once per wave and stay in registers.  The accumulator has the 32 output channels on the lanes, so every
+// store instruction writes two whole 128-byte pixel rows.  HBM-bound (3.15 MB in + 8.4 MB out per 512^2 image) where the
+// VALU kernel above was bound by its 27 ds_bpermute + 108 FMA per 4 outputs.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__global__ __launch_bounds__(256) void conv3x3_stem_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                const float* __restrict__ bias, float* __restrict__ y, int batch,
+                                                                int h_in, int w_in, int stride, int pad_top, int pad_left,
+                                                                int h_out, int w_out, int ldx, int ldy, int relu) {
+    constexpr int COUT = 32, NE = 27;
+    const int lane = threadIdx.x & 63, l32 = lane & 31, hh = lane >> 5;
+    // k slot (s, j) of this lane half holds input element e = 16 s + 8 hh + j, e = (ky * 3 + kx) * 3 + ci
+    f16x8 bh[2], bl[2];
+    int off[16], kyx[16];                                     // element offset from the window origin; ky | kx << 2 | valid << 4
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int e = 16 * (k >> 3) + 8 * hh + (k & 7);
+        const bool ok = e < NE;
+        const int ec = ok ? e : 0;
+        const int tap = ec / 3, ci = ec - tap * 3, ky = tap / 3, kx = tap - ky * 3;
+        off[k] = (ky * w_in + kx) * ldx + ci;
+        kyx[k] = ky | (kx << 2) | ((int)ok << 4);
+        const float wv = ok ? w[ec * COUT + l32] : 0.0f;
+        const _Float16 hi = (_Float16)wv;
+        bh[k >> 3][k & 7] = hi;
+        bl[k >> 3][k & 7] = (_Float16)(wv - (float)hi);
+    }
+    const float bv = bias[l32];
+    const int groups_x = (w_out + 31) / 32;
+    const long long total = (long long)batch * h_out * groups_x;
+    for (long long g = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); g < total; g += (long long)gridDim.x * 4) {
+        const int gx = (int)(g % groups_x);
+        const long long t = g / groups_x;
+        const int oy = (int)(t % h_out);
+        const long long b = t / h_out;
+        const int ox = gx * 32 + l32;
+        const int iy0 = oy * stride - pad_top, ix0 = ox * stride - pad_left;
+        const float* xin = x + b * h_in * w_in * ldx;
+        const long long org = ((long long)iy0 * w_in + ix0) * ldx;
+        float a[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int iy = iy0 + (kyx[k] & 3), ix = ix0 + ((kyx[k] >> 2) & 3);
+            const bool in = (kyx[k] & 16) && ox < w_out && iy >= 0 && iy < h_in && ix >= 0 && ix < w_in;
+            const float v = xin[in ? org + off[k] : 0];
+            a[k] = in ? v : 0.0f;
+        }
+        f16x8 ah[2], al[2];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const _Float16 hi = (_Float16)a[k];
+            ah[k >> 3][k & 7] = hi;
+            al[k >> 3][k & 7] = (_Float16)(a[k] - (float)hi);
+        }
+        f32x16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s], bh[s], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], bl[s], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], bh[s], acc, 0, 0, 0);
+        }
+        // C/D map: column (output channel) = lane & 31, row (pixel) = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)
+        float* yrow = y + ((b * h_out + oy) * w_out + (long long)gx * 32) * ldy + l32;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int r = (e & 3) + 8 * (e >> 2) + 4 * hh;
+            float v = acc[e] + bv;
+            if (relu) v = fmaxf(v, 0.f);
+            if (relu == 2) v = fminf(v, 6.f);
+            if (gx * 32 + r < w_out) yrow[(long long)r * ldy] = v;
+        }
+    }
+}
+
 // ---- global average pool: block = 64 channel-quads x 4 pixel groups ----------------------------
 __global__ __launch_bounds__(256) void gap_kernel(const float* __restrict__ x, float* __restrict__ y, int hw, int c, int ldx) {
     __shared__ f32x4 part[4][64];
@@ -200,6 +283,24 @@ extern "C" int asr_conv3x3_direct_f32(const float* x, const float* w, const floa
     hipLaunchKernelGGL(conv3x3_direct_kernel, dim3(cap_grid(total)), dim3(256), sizeof(float) * 9 * cin * cout,
                        asr_stream(stream), x, w, bias, y, batch, h_in, w_in, cin, cout, stride, pad_top, pad_left, h_out,
                        w_out, ldx, ldy, relu);
+    ASR_LAUNCH_CHECK();
+    return ASR_OK;
+}
+
+extern "C" int asr_conv3x3_stem_f16x3(const float* x, const float* w, const float* bias, float* y, int batch, int h_in, int w_in,
+                                      int cin, int cout, int stride, int pad_top, int pad_left, int h_out, int w_out, int ldx,
+                                      int ldy, int relu, asr_stream_t stream) {
+    ASR_REQUIRE(x && w && bias && y, "asr_conv3x3_stem_f16x3: null pointer");
+    ASR_REQUIRE(batch > 0 && h_in > 0 && w_in > 0 && stride > 0 && h_out > 0 && w_out > 0 && pad_top >= 0 && pad_left >= 0 &&
+                    ldx >= cin && ldy >= cout,
+                "asr_conv3x3_stem_f16x3: bad geometry");
+    ASR_UNSUPPORTED(cin != 3 || cout != 32, "asr_conv3x3_stem_f16x3: cin = 3, cout = 32 only (got %d, %d)", cin, cout);
+    ASR_REQUIRE((h_out - 1) * stride - pad_top + 2 < h_in + 2 && (w_out - 1) * stride - pad_left + 2 < w_in + 2,
+                "asr_conv3x3_stem_f16x3: output %dx%d does not fit input %dx%d", h_out, w_out, h_in, w_in);
+    ASR_UNSUPPORTED((long long)h_in * w_in * ldx > 0x7fffffffLL, "asr_conv3x3_stem_f16x3: image too large");
+    const long long waves = (long long)batch * h_out * asr_cdiv(w_out, 32);
+    hipLaunchKernelGGL(conv3x3_stem_mfma_kernel, dim3(cap_grid(waves * 64)), dim3(256), 0, asr_stream(stream), x, w, bias, y,
+                       batch, h_in, w_in, stride, pad_top, pad_left, h_out, w_out, ldx, ldy, relu);
     ASR_LAUNCH_CHECK();
     return ASR_OK;
 }

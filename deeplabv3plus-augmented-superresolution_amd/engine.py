@@ -294,7 +294,8 @@ class DeeplabEngine:
             p = self.p["Conv"]
             c0 = p["n"]
             a1 = new((B, h1, w1, c0))
-            add("asr_conv3x3_direct_f32", (x_in.ptr, p["w"].data_ptr(), p["b"].data_ptr(), a1.ptr, B, H, Wd, 3, c0, 2, pt, pl,
+            add("asr_conv3x3_stem_f16x3" if (self.precision == "f16x3" and c0 == 32) else "asr_conv3x3_direct_f32",
+                (x_in.ptr, p["w"].data_ptr(), p["b"].data_ptr(), a1.ptr, B, H, Wd, 3, c0, 2, pt, pl,
                                            h1, w1, 3, a1.ld, 2), "conv", 2.0 * B * h1 * w1 * 27 * c0,
                 4.0 * (B * H * Wd * 3 + B * h1 * w1 * c0), label="Conv", out=a1)
             t = dw(a1, "expanded_conv_depthwise", 1, 1, False, 2)
@@ -333,7 +334,8 @@ class DeeplabEngine:
         # ---- entry flow (model.py:149-170) ----
         a1 = new((B, h1, w1, 32))
         p = self.p["entry_flow_conv1_1"]
-        add("asr_conv3x3_direct_f32", (x_in.ptr, p["w"].data_ptr(), p["b"].data_ptr(), a1.ptr, B, H, Wd, 3, 32, 2, pt, pl,
+        add("asr_conv3x3_stem_f16x3" if self.precision == "f16x3" else "asr_conv3x3_direct_f32",
+            (x_in.ptr, p["w"].data_ptr(), p["b"].data_ptr(), a1.ptr, B, H, Wd, 3, 32, 2, pt, pl,
                                        h1, w1, 3, 32, 1), "conv", 2.0 * B * h1 * w1 * 27 * 32,
             4.0 * (B * H * Wd * 3 + B * h1 * w1 * 32))
         a2 = new((B, h1, w1, 64))

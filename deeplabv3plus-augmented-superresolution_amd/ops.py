@@ -364,12 +364,13 @@ def conv3x3_mfma(x, w_packed, bias, cout, stride=1, pad=1, dil=1, relu=False, f1
     return y
 
 
-def conv3x3_direct(x, w_hwio, bias, stride, pad_top, pad_left, out_hw, relu=False):
+def conv3x3_direct(x, w_hwio, bias, stride, pad_top, pad_left, out_hw, relu=False, f16x3=False):
+    """Dense 3x3 for tiny cin (the stem).  f16x3=True: the split-f16 MFMA form (cin = 3, cout = 32 only)."""
     b, h, w, cin = x.shape
     cout = w_hwio.shape[-1]
     y = torch.empty((b, out_hw[0], out_hw[1], cout), dtype=f32, device=x.device)
-    call("asr_conv3x3_direct_f32", ptr(x), ptr(w_hwio), ptr(bias), ptr(y), b, h, w, cin, cout, stride, pad_top,
-         pad_left, out_hw[0], out_hw[1], cin, cout, int(relu), stream_ptr())
+    call("asr_conv3x3_stem_f16x3" if f16x3 else "asr_conv3x3_direct_f32", ptr(x), ptr(w_hwio), ptr(bias), ptr(y), b, h, w, cin,
+         cout, stride, pad_top, pad_left, out_hw[0], out_hw[1], cin, cout, int(relu), stream_ptr())
     return y
 
 

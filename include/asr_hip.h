@@ -294,6 +294,12 @@ int asr_conv3x3_direct_f32(const float* x, const float* w, const float* bias, fl
                            int cin, int cout, int stride, int pad_top, int pad_left, int h_out, int w_out, int ldx,
                            int ldy, int relu, asr_stream_t stream);
 
+/* The same layer (cin = 3, cout = 32 only) as an implicit GEMM on split-f16 MFMA (K = 27 padded to 32; hi*hi + hi*lo +
+ * lo*hi with f32 accumulation: f32-grade results, like asr_pwconv_mfma_f16x3).  Same arguments. */
+int asr_conv3x3_stem_f16x3(const float* x, const float* w, const float* bias, float* y, int batch, int h_in, int w_in,
+                           int cin, int cout, int stride, int pad_top, int pad_left, int h_out, int w_out, int ldx,
+                           int ldy, int relu, asr_stream_t stream);
+
 /* DepthwiseConv2D 3x3 (+ ZeroPadding2D, folded BN, ReLU before and/or after): the depthwise half
  * of _SepConv_BN, model.py:478-495, and of _inverted_res_block, model.py:442-449 (post_relu = 2: ReLU6).
  * w [3,3,c] with the BN scale folded, bias [c].

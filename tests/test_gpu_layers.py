@@ -126,8 +126,10 @@ def test_conv3x3_mfma_matches_conv2d(dev, f16x3, cin, cout):
     assert np.max(np.abs(got - ref) / (mag + 1e-30)) <= 4e-6
 
 
-def test_conv3x3_direct_same_padding_stride2(dev):
-    """entry_flow_conv1_1: 'same' + stride 2 on an even input pads bottom/right only."""
+@pytest.mark.parametrize("f16x3", [False, True])
+def test_conv3x3_direct_same_padding_stride2(dev, f16x3):
+    """entry_flow_conv1_1: 'same' + stride 2 on an even input pads bottom/right only; the VALU kernel and the
+    split-f16 MFMA implicit GEMM (ragged width: 24 of a 32-pixel wave group)."""
     from asr_amd import ops
     rng = np.random.default_rng(13)
     b, h, w_, cin, cout = 2, 32, 48, 3, 32
@@ -138,14 +140,20 @@ def test_conv3x3_direct_same_padding_stride2(dev):
     ref = F.conv2d(xt, torch.from_numpy(k).permute(3, 2, 0, 1), torch.from_numpy(bias), stride=2).relu()
     ref = ref.permute(0, 2, 3, 1).numpy()
     got = ops.conv3x3_direct(ops.to_device(x), ops.to_device(k), ops.to_device(bias), 2, 0, 0, (h // 2, w_ // 2),
-                             relu=True).cpu().numpy()
+                             relu=True, f16x3=f16x3).cpu().numpy()
     np.testing.assert_allclose(got, ref, rtol=1e-5, atol=1e-5)
+    # stride 1, symmetric padding, a width that spans several wave groups with a ragged tail
+    x1 = _rand(rng, 1, 9, 70, cin)
+    ref1 = F.conv2d(torch.from_numpy(x1).permute(0, 3, 1, 2), torch.from_numpy(k).permute(3, 2, 0, 1), torch.from_numpy(bias),
+                    padding=1).permute(0, 2, 3, 1).numpy()
+    got1 = ops.conv3x3_direct(ops.to_device(x1), ops.to_device(k), ops.to_device(bias), 1, 1, 1, (9, 70), f16x3=f16x3).cpu().numpy()
+    np.testing.assert_allclose(got1, ref1, rtol=1e-5, atol=1e-5)
     # impulse at the last pixel only reaches the last output pixel (asymmetric padding check)
     imp = np.zeros((1, 8, 8, 3), np.float32)
     imp[0, 7, 7, 0] = 1.0
     g = ops.conv3x3_direct(ops.to_device(imp), ops.to_device(k), ops.to_device(np.zeros(cout, np.float32)), 2, 0, 0,
-                           (4, 4)).cpu().numpy()
-    assert np.count_nonzero(np.abs(g).sum(-1)) == 1 and np.allclose(g[0, 3, 3], k[1, 1, 0])
+                           (4, 4), f16x3=f16x3).cpu().numpy()
+    assert np.count_nonzero(np.abs(g).sum(-1)) == 1 and np.allclose(g[0, 3, 3], k[1, 1, 0], rtol=1e-6, atol=1e-7)
 
 
 def _dw_ref(x, k, bias, stride, rate, pad, pre, post):
