@@ -3,8 +3,9 @@
 ``compute_SR`` (:213-273), ``list_precomputed_data_paths`` / ``check_validity`` for the two-stage
 workflow, and the dataset-list helpers (``get_img_paths`` :9-29, ``class_in_image`` :32-38,
 ``filter_images_by_class`` :41-53, ``load_precomputed_images`` :65-78, ``get_precomputed_folders_path`` :81-90,
-``normalize_coefficients`` :142-151).  The interchange file is an ``.npz`` with the reference's HDF5 dataset and
-attribute names (h5py is not available in this image).
+``normalize_coefficients`` :142-151).  The interchange file is the reference's HDF5 file (same dataset and
+attribute names, written / read by ``hdf5_lite``: files from the reference's h5py writer load here and vice versa);
+an ``.npz`` with the same keys is accepted too (``ASR_DATA_EXT=.npz`` makes it the written format).
 """
 from __future__ import annotations
 
@@ -13,9 +14,10 @@ import os
 import numpy as np
 import torch
 
-from .. import _lib, ops
+from .. import _lib, hdf5_lite, ops
 
-DATA_EXT = ".npz"
+DATA_EXT = os.environ.get("ASR_DATA_EXT", ".hdf5")          # what save_SR_data writes: ".hdf5" (reference) or ".npz"
+DATA_EXTS = (".hdf5", ".h5", ".npz")                         # what the readers accept
 
 
 def get_img_paths(image_list_path, image_folder, is_png=False, sort=True):
@@ -108,22 +110,39 @@ def threshold_image(image, th_value, th_factor=.15, th_mask=None):
 
 
 # ---- interchange file (augmentation_utils.py:117-136 writer, superres_utils.py:154-210 reader) -------
-def save_SR_data(path_without_ext, class_masks, max_masks, angles, shifts, filename, mode, angle_max, shift_max):
+def save_SR_data(path_without_ext, class_masks, max_masks, angles, shifts, filename, mode, angle_max, shift_max, ext=None):
+    ext = ext or DATA_EXT
     os.makedirs(os.path.dirname(path_without_ext) or ".", exist_ok=True)
     data = dict(class_masks=np.asarray(class_masks, dtype=np.float32), angles=np.asarray(angles, dtype=np.float32),
-                shifts=np.asarray(shifts, dtype=np.float32), filename=np.array(filename), mode=np.array(mode),
-                angle_max=np.array(angle_max), shift_max=np.array(shift_max))
+                shifts=np.asarray(shifts, dtype=np.float32))
     if max_masks is not None and len(max_masks):
         data["max_masks"] = np.asarray(max_masks, dtype=np.float32)
-    np.savez(path_without_ext + DATA_EXT, **data)
-    return path_without_ext + DATA_EXT
+    attrs = dict(filename=str(filename), mode=str(mode), angle_max=angle_max, shift_max=shift_max)
+    if ext == ".npz":
+        np.savez(path_without_ext + ext, **data, **{k: np.array(v) for k, v in attrs.items()})
+    elif ext in (".hdf5", ".h5"):
+        hdf5_lite.write(path_without_ext + ext, data, attrs)
+    else:
+        raise ValueError(f"unknown interchange format {ext!r} (.hdf5 or .npz)")
+    return path_without_ext + ext
+
+
+def _open_SR_file(filepath):
+    """-> dict with the datasets plus the attributes 'filename' and 'mode' (either container format)."""
+    if str(filepath).endswith(".npz"):
+        with np.load(filepath, allow_pickle=False) as z:
+            return {k: z[k] for k in z.files}
+    datasets, attrs = hdf5_lite.read(filepath)
+    out = dict(datasets)
+    out.update(attrs.get("/", {}))
+    return out
 
 
 def list_precomputed_data_paths(root_dir, sort=False):
     paths = []
     for path, _subdirs, files in os.walk(root_dir):
         for filename in files:
-            if filename.endswith(DATA_EXT):
+            if filename.endswith(DATA_EXTS):
                 paths.append(os.path.join(path, filename))
     if sort:
         paths = sorted(paths, key=lambda p: int(os.path.basename(p).split('.')[0]))
@@ -141,15 +160,15 @@ def check_validity(file, num_aug=100):
 def load_SR_data(filepath, num_aug=100, global_normalize=True):
     """Returns (class_masks [N,h,w,1], max_masks | None, angles, shifts, filename) as host arrays;
     argmax / slice_max masks are min-max normalised to [0,1] (superres_utils.py:183-206)."""
-    with np.load(filepath, allow_pickle=False) as file:
-        if not check_validity(file, num_aug=num_aug):
-            raise Exception(f"File: {filepath} is invalid")
-        filename = str(file["filename"])
-        mode = str(file["mode"])
-        angles = file["angles"][:num_aug]
-        shifts = file["shifts"][:num_aug]
-        class_masks = file["class_masks"][:num_aug].astype(np.float32)
-        max_masks = file["max_masks"][:num_aug].astype(np.float32) if mode == "slice_max" else None
+    file = _open_SR_file(filepath)
+    if not check_validity(file, num_aug=num_aug):
+        raise Exception(f"File: {filepath} is invalid")
+    filename = str(file["filename"])
+    mode = str(file["mode"])
+    angles = file["angles"][:num_aug]
+    shifts = file["shifts"][:num_aug]
+    class_masks = file["class_masks"][:num_aug].astype(np.float32)
+    max_masks = file["max_masks"][:num_aug].astype(np.float32) if mode == "slice_max" else None
 
     def normalise(stack):
         if global_normalize:

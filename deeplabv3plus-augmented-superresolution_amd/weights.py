@@ -207,13 +207,28 @@ def save_weights(path, weights):
 
 
 def load_weights(path):
-    """Local .npz only (``{layer}/{variable}`` keys).  Never a URL: the reference's get_file()
+    """Local file only: an .npz with ``{layer}/{variable}`` keys, or a Keras ``.h5`` weight file (the format of the
+    bonlime checkpoint the reference downloads, model.py:129-145: groups ``<layer>/<layer>/<variable>:0``), read with
+    hdf5_lite and matched by layer name like ``load_weights(by_name=True)``.  Never a URL: the reference's get_file()
     download (model.py:134-143) has no offline counterpart."""
     if str(path).startswith(("http://", "https://")):
         raise ValueError("weights must be a local file; network downloads are not supported")
     if str(path).endswith((".h5", ".hdf5")):
-        raise ValueError("HDF5 weight files need h5py, which is not available here: export the Keras weights to "
-                         ".npz with keys '<layer name>/<variable name>'")
+        from . import hdf5_lite
+        datasets, _ = hdf5_lite.read(path)
+        out = {}
+        for name, value in datasets.items():
+            parts = name.split("/")
+            if parts[0] in ("model_weights", "optimizer_weights"):      # full-model .h5: weights live one level down
+                if parts[0] == "optimizer_weights":
+                    continue
+                parts = parts[1:]
+            if len(parts) < 2:
+                continue
+            out[f"{parts[0]}/{parts[-1].split(':')[0]}"] = np.asarray(value)
+        if not out:
+            raise ValueError(f"{path}: no '<layer>/.../<variable>' datasets found")
+        return out
     with np.load(path) as z:
         return {k: z[k] for k in z.files}
 

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Batch producer: augmented copies -> DeepLabV3+ -> OPM -> one interchange file per image.  Counterpart of
 the reference's generate_augmented_copies.py (same flags); images are listed with --images (a folder or
-a text file of paths) instead of the VOC file lists, and files are .npz (h5py is not available).
+a text file of paths) instead of the VOC file lists; files are the reference's {image}.hdf5 (asr_amd/hdf5_lite.py).
 With one process per GPU (torch.distributed.run) images are dealt round-robin over the ranks while every
 rank replays the reference's sequential RNG stream, so each image gets the reference's draws."""
 import argparse
@@ -23,7 +23,7 @@ parser.add_argument("--shift_max", help="Max shift value used for traslations", 
 parser.add_argument("--backbone", type=str, choices=["mobilenet", "xception"], default="xception")
 parser.add_argument("--use_validation", action="store_true")
 parser.add_argument("--class_id", type=int, default=8, choices=range(21), required=True)
-parser.add_argument("--weights", default=None, help="local .npz of Keras weights")
+parser.add_argument("--weights", default=None, help="local Keras .h5 checkpoint or .npz of Keras weights")
 parser.add_argument("--out_root", default=os.path.join(ROOT, "data", "superres_root", "augmented_copies"))
 
 SEED = 1234

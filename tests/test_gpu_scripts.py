@@ -30,7 +30,7 @@ def test_two_stage_scripts(dev, golden_dir, tmp_path):
           "--mode", "argmax", "--angle_max", "0.15", "--shift_max", "80", "--class_id", "8", "--out_root", str(out_root)],
          str(tmp_path))
     data_dir = out_root / "xception_argmax_8_4"
-    assert (data_dir / "7.npz").exists()
+    assert (data_dir / "7.hdf5").exists()
     std_root = tmp_path / "standard"
     _run([os.path.join(ROOT, "scripts", "generate_standard_output.py"), "--images", str(imgs), "--class_id", "8",
           "--out_root", str(std_root)], str(tmp_path))

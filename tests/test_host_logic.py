@@ -147,8 +147,8 @@ def test_weight_inventory_and_folding():
     assert k.shape == (2048, 256) and b.shape == (256,)
     with pytest.raises(ValueError):
         W.load_weights("https://example.com/w.h5")
-    with pytest.raises(ValueError):
-        W.load_weights("/tmp/w.h5")
+    with pytest.raises(FileNotFoundError):                       # a local .h5 is opened (hdf5_lite), not refused
+        W.load_weights("/tmp/definitely_missing_weights.h5")
 
 
 def test_dataset_list_helpers(tmp_path):
