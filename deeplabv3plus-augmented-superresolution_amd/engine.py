@@ -77,8 +77,12 @@ def _same_pad(in_size, k_eff, stride):
 class DeeplabEngine:
     """Folded / packed parameters on the device + per-(batch, H, W) launch plans."""
 
-    def __init__(self, weights: dict, classes=21, device=None, precision=None, backbone="xception", alpha=1.0, OS=16):
-        """precision: 'f32' = v_mfma_f32_32x32x2_f32 everywhere (exact f32 fmaf chains);
+    def __init__(self, weights: dict, classes=21, device=None, precision=None, backbone="xception", alpha=1.0, OS=16,
+                 decoder="full", first_upsample_size=(128, 128), class_prediction=True):
+        """decoder: "full" | "dcnn" | "aspp" = Decoder / Decoder_only_DCNN / Decoder_only_ASPP (model.py:235-294; the
+        last two resize to first_upsample_size instead of the skip's size); class_prediction=False returns the decoder's
+        256-channel features instead of the logits (model.py:104-106).
+        precision: 'f32' = v_mfma_f32_32x32x2_f32 everywhere (exact f32 fmaf chains);
         'f16x3' = split-f16 MFMA (hi*hi + hi*lo + lo*hi, f32 accumulate; f32-grade results, ~2.4x faster)
         for the pointwise GEMMs with more than 64 output channels.  Default: $ASR_PRECISION or 'f16x3'."""
         self.device = device or _lib.require_gpu()
@@ -97,6 +101,13 @@ class DeeplabEngine:
             ((1, 2, (2, 4), (12, 24, 36)) if self.OS == 8 else (2, 1, (1, 2), (6, 12, 18)))
         self.output_stride = 4 if backbone == "xception" else 8      # input size / logits size
         self.classes = classes
+        if decoder not in ("full", "dcnn", "aspp"):
+            raise ValueError(f"decoder must be 'full', 'dcnn' or 'aspp', got {decoder!r}")
+        if backbone != "xception" and decoder != "full":
+            raise ValueError("the modified decoders exist for the xception backbone only (model.py:80)")
+        self.decoder = decoder
+        self.first_upsample_size = tuple(int(v) for v in first_upsample_size)
+        self.class_prediction = bool(class_prediction)
         self.logits_name = "logits_semantic" if "logits_semantic/kernel" in weights else "custom_logits_semantic"
         self.p = {}
         self._plans = {}
@@ -160,18 +171,25 @@ class DeeplabEngine:
                 self._put_sep(f"{prefix}_separable_conv{i + 1}", e3)
             if skip == "conv":
                 self._put_conv(prefix + "_shortcut", prefix + "_shortcut_BN", e3)
-        self._put_conv("image_pooling", "image_pooling_BN", e5)
-        self._put_conv("aspp0", "aspp0_BN", e5)
-        for i in (1, 2, 3):
-            self._put_sep(f"aspp{i}", e3)
-        # branch-major stack of the three folded ASPP depthwise kernels for the fused kernel
-        self.p["aspp_dw3"] = dict(w=torch.stack([self.p[f"aspp{i}_depthwise"]["w"] for i in (1, 2, 3)]).contiguous(),
-                                  b=torch.stack([self.p[f"aspp{i}_depthwise"]["b"] for i in (1, 2, 3)]).contiguous())
-        self._put_conv("concat_projection", "concat_projection_BN", e5)
-        self._put_conv("feature_projection0", "feature_projection0_BN", e5)
+        if self.decoder != "dcnn":      # Decoder_only_DCNN never reaches the ASPP (Keras drops layers off the output's path)
+            self._put_conv("image_pooling", "image_pooling_BN", e5)
+            self._put_conv("aspp0", "aspp0_BN", e5)
+            for i in (1, 2, 3):
+                self._put_sep(f"aspp{i}", e3)
+            # branch-major stack of the three folded ASPP depthwise kernels for the fused kernel
+            self.p["aspp_dw3"] = dict(w=torch.stack([self.p[f"aspp{i}_depthwise"]["w"] for i in (1, 2, 3)]).contiguous(),
+                                      b=torch.stack([self.p[f"aspp{i}_depthwise"]["b"] for i in (1, 2, 3)]).contiguous())
+            self._put_conv("concat_projection", "concat_projection_BN", e5)
+        if self.decoder != "aspp":
+            self._put_conv("feature_projection0", "feature_projection0_BN", e5)
         self._put_sep("decoder_conv0", e5)
         self._put_sep("decoder_conv1", e5)
-        self._put_conv(self.logits_name, None, None)
+        if self.class_prediction:
+            self._put_conv(self.logits_name, None, None)
+        want = {"full": 304, "dcnn": 48, "aspp": 256}[self.decoder]
+        if self.p["decoder_conv0_depthwise"]["c"] != want:
+            raise ValueError(f"decoder_conv0_depthwise has {self.p['decoder_conv0_depthwise']['c']} channels; the "
+                             f"'{self.decoder}' decoder needs {want} (weights built for another decoder?)")
         torch.cuda.synchronize(self.device)
         del self._w
 
@@ -353,8 +371,14 @@ class DeeplabEngine:
         # ---- exit flow (model.py:181-190) ----
         x = block(x, "exit_flow_block1", "conv", 1, self.exit_block_rates[0], False)
         x = block(x, "exit_flow_block2", None, 1, self.exit_block_rates[1], True)
-        # ---- ASPP (model.py:192-233) ----
         b, fh, fw, fc = x.shape
+        if self.decoder == "dcnn":
+            # ---- Decoder_only_DCNN (model.py:261-280): the encoder output goes straight to the 48-channel projection ----
+            release(skip)
+            feat = pw(x, "feature_projection0", relu=True)
+            release(x)
+            return self._finish_plan(feat, 48, None, steps, outs, pool, x_in, new, release, add, pw, sepconv, B)
+        # ---- ASPP (model.py:192-233) ----
         cat = new((b, fh, fw, 1280))
         pooled = new((b, 1, 1, fc), pad=False)
         add("asr_gap_f32", (x.ptr, pooled.ptr, b, fh * fw, fc, x.ld), "misc", b * fh * fw * fc, 4.0 * b * fh * fw * fc,
@@ -398,23 +422,39 @@ class DeeplabEngine:
         release(x)
         x = pw(cat, "concat_projection", relu=True)
         release(cat)
-        # ---- decoder (model.py:235-259) ----
-        sb, sh, sw, sc_ = skip.shape
-        cat2 = new((sb, sh, sw, 304))
-        add("asr_resize_bilinear_f32", (x.ptr, cat2.ptr, b, fh, fw, 256, sh, sw, x.ld, cat2.ld), "misc", 0,
-            4.0 * sb * sh * sw * 256)
-        release(x)
-        pw(skip, "feature_projection0", out=cat2, out_off=256, relu=True)
-        release(skip)
+        if self.decoder == "aspp":     # Decoder_only_ASPP (model.py:282-294): no skip connection
+            release(skip)
+            skip = None
+        return self._finish_plan(x, 256, skip, steps, outs, pool, x_in, new, release, add, pw, sepconv, B)
+
+    def _finish_plan(self, feat, fch, skip, steps, outs, pool, x_in, new, release, add, pw, sepconv, B):
+        """Decoder tail shared by the three decoders: resize -> [concat the projected skip] -> decoder_conv0/1 ->
+        [logits] (model.py:235-306)."""
+        b, fh, fw, _ = feat.shape
+        if skip is not None:
+            sb, sh, sw, _ = skip.shape
+            cat2 = new((sb, sh, sw, 304))
+        else:
+            sh, sw = self.first_upsample_size          # Resizing(*first_upsample_size) (model.py:271-272, 285-286)
+            cat2 = new((b, sh, sw, fch))
+        add("asr_resize_bilinear_f32", (feat.ptr, cat2.ptr, b, fh, fw, fch, sh, sw, feat.ld, cat2.ld), "misc", 0,
+            4.0 * b * sh * sw * fch)
+        release(feat)
+        if skip is not None:
+            pw(skip, "feature_projection0", out=cat2, out_off=256, relu=True)
+            release(skip)
         x = sepconv(cat2, "decoder_conv0", 1, 1, True)
         release(cat2)
         y = sepconv(x, "decoder_conv1", 1, 1, True)
         release(x)
-        logits = pw(y, self.logits_name, pad_out=False)
-        release(y)
-        plan = dict(steps=steps, outs=outs, pool=pool, x_in=x_in, logits=logits, pool_bytes=pool.total_bytes,
-                    out_shape=(B, sh, sw, self.classes))
-        return plan
+        if self.class_prediction:
+            logits = pw(y, self.logits_name, pad_out=False)
+            release(y)
+            channels = self.classes
+        else:
+            logits, channels = y, y.shape[-1]         # model.py:104-106: the decoder's features are the output
+        return dict(steps=steps, outs=outs, pool=pool, x_in=x_in, logits=logits, pool_bytes=pool.total_bytes,
+                    out_shape=(B, sh, sw, channels))
 
     def plan(self, B, H, Wd, lane=0):
         """lane: independent activation pools for forward passes that run concurrently on different HIP streams."""

@@ -3,8 +3,9 @@
 
 Scope: Xception backbone at OS=16 or OS=8 (model.py:42-52) and the MobileNetV2 backbone
 (always OS=8, model.py:53-55), ``classes`` logits, ``final_upsample`` on or off, ``last_activation`` None /
-softmax / sigmoid, ``reshape_outputs``.  The ``only_*`` decoders and ``final_class_prediction=False`` are validated
-like the reference and then rejected with NotImplementedError (not on the hot path).
+softmax / sigmoid, ``reshape_outputs``, the modified decoders ``only_DCNN_output`` / ``only_ASPP_output`` with
+``first_upsample_size`` (model.py:261-294, Xception only) and ``final_class_prediction=False`` (the decoder's 256-channel
+features as the output, model.py:100-106).
 """
 from __future__ import annotations
 
@@ -51,16 +52,20 @@ class DeeplabV3Plus:
                     final_upsample=True, final_class_prediction=True):
         if self.backbone == "xception" and only_DCNN_output is True and only_ASPP_output is True:
             raise ValueError("Both only_DCNN_output and only_ASPP_output cannot be True at the same time")
-        if only_DCNN_output or only_ASPP_output or not final_class_prediction:
-            raise NotImplementedError("alternative decoders are not on the accelerated path")
+        # model.py:80-93: the modified decoders exist for the xception backbone only (the flags are ignored for mobilenet)
+        decoder = "full"
+        if self.backbone == "xception":
+            decoder = "dcnn" if only_DCNN_output else ("aspp" if only_ASPP_output else "full")
         if self.load_weights and self.weights_path is not None:
             params = W.load_weights(self.weights_path)          # local file only (never the URL of model.py:9)
         else:
             # The pretrained .h5 is a network download (model.py:134-143): unavailable offline.
-            params = W.make_synthetic_weights(self.synthetic_seed, self.classes, backbone=self.backbone, alpha=self.alpha)
+            params = W.make_synthetic_weights(self.synthetic_seed, self.classes, backbone=self.backbone, alpha=self.alpha,
+                                              decoder=decoder, class_prediction=final_class_prediction)
         return DeeplabModel(params, self.input_shape, self.classes, final_upsample, self.last_activation,
                             precision=self.precision, backbone=self.backbone, alpha=self.alpha, OS=self.OS,
-                            reshape_outputs=self.reshape_outputs)
+                            reshape_outputs=self.reshape_outputs, decoder=decoder, first_upsample_size=first_upsample_size,
+                            class_prediction=final_class_prediction)
 
 
 class DeeplabModel:
@@ -68,15 +73,21 @@ class DeeplabModel:
     (augmentation_utils.py:76)."""
 
     def __init__(self, params, input_shape, classes, final_upsample, last_activation, precision=None,
-                 backbone="xception", alpha=1.0, OS=16, reshape_outputs=False):
+                 backbone="xception", alpha=1.0, OS=16, reshape_outputs=False, decoder="full",
+                 first_upsample_size=(128, 128), class_prediction=True):
         self.input_shape = tuple(input_shape)
         self.reshape_outputs = reshape_outputs
         self.classes = classes
         self.final_upsample = final_upsample
         self.last_activation = last_activation
         self.backbone = backbone
-        self.name = f"DLV3Plus-{backbone}-OS{OS if backbone == 'xception' else 8}"      # model.py:71
-        self.engine = DeeplabEngine(params, classes, precision=precision, backbone=backbone, alpha=alpha, OS=OS)
+        prefix = f"DLV3Plus-{backbone}-OS{OS if backbone == 'xception' else 8}"          # model.py:71, 85-106
+        self.name = prefix + {"full": "", "dcnn": "-Only_DCNN_Output", "aspp": "-Only_ASPP_Output"}[decoder]
+        if not class_prediction:
+            self.name = prefix + "-no_class_prediction"
+        self.engine = DeeplabEngine(params, classes, precision=precision, backbone=backbone, alpha=alpha, OS=OS,
+                                    decoder=decoder, first_upsample_size=first_upsample_size,
+                                    class_prediction=class_prediction)
         self.precision = self.engine.precision
         self.device = self.engine.device
 
@@ -102,7 +113,7 @@ class DeeplabModel:
             # model.py:120-122: Reshape((input_h * input_w, classes)) -- only meaningful with final_upsample, like the reference
             if out.shape[1] * out.shape[2] != self.input_shape[0] * self.input_shape[1]:
                 raise ValueError("reshape_outputs needs the model output at the input size (final_upsample=True)")
-            out = out.reshape(out.shape[0], self.input_shape[0] * self.input_shape[1], self.classes)
+            out = out.reshape(out.shape[0], self.input_shape[0] * self.input_shape[1], out.shape[-1])
         if self.last_activation in ("softmax", "sigmoid"):
             out = ops.class_activation(out.contiguous(), self.last_activation)
         return out

@@ -95,8 +95,13 @@ def mobilenet_inventory(classes=21, alpha=1.0):
     return inv
 
 
-def layer_inventory(classes=21, backbone="xception", alpha=1.0):
-    """Ordered list of (kind, name, shape-info dict).  kinds: conv, dw, bn."""
+def layer_inventory(classes=21, backbone="xception", alpha=1.0, decoder="full", class_prediction=True):
+    """Ordered list of (kind, name, shape-info dict).  kinds: conv, dw, bn.
+    decoder: "full" (Decoder, model.py:235-259), "dcnn" (Decoder_only_DCNN, :261-280: feature_projection0 takes the
+    2048-channel encoder output, decoder_conv0 48 channels) or "aspp" (Decoder_only_ASPP, :282-294: decoder_conv0 takes
+    the 256-channel ASPP output); Xception only."""
+    if decoder not in ("full", "dcnn", "aspp"):
+        raise ValueError(f"decoder must be 'full', 'dcnn' or 'aspp', got {decoder!r}")
     if backbone == "mobilenet":
         return mobilenet_inventory(classes, alpha)
     inv = []
@@ -133,17 +138,19 @@ def layer_inventory(classes=21, backbone="xception", alpha=1.0):
         sep(f"aspp{i}", 2048, 256, XCEPTION_BN_EPS)
     conv("concat_projection", 1, 1280, 256)
     bn("concat_projection_BN", 256, HEAD_BN_EPS)
-    conv("feature_projection0", 1, 256, 48)
-    bn("feature_projection0_BN", 48, HEAD_BN_EPS)
-    sep("decoder_conv0", 304, 256, HEAD_BN_EPS)
+    if decoder != "aspp":
+        conv("feature_projection0", 1, 2048 if decoder == "dcnn" else 256, 48)
+        bn("feature_projection0_BN", 48, HEAD_BN_EPS)
+    sep("decoder_conv0", {"full": 304, "dcnn": 48, "aspp": 256}[decoder], 256, HEAD_BN_EPS)
     sep("decoder_conv1", 256, 256, HEAD_BN_EPS)
-    conv("logits_semantic" if classes == 21 else "custom_logits_semantic", 1, 256, classes, bias=True)
+    if class_prediction:
+        conv("logits_semantic" if classes == 21 else "custom_logits_semantic", 1, 256, classes, bias=True)
     return inv
 
 
-def count_params(classes=21, backbone="xception", alpha=1.0):
+def count_params(classes=21, backbone="xception", alpha=1.0, decoder="full"):
     n = 0
-    for kind, _name, d in layer_inventory(classes, backbone, alpha):
+    for kind, _name, d in layer_inventory(classes, backbone, alpha, decoder):
         if kind == "conv":
             n += d["kh"] * d["kh"] * d["cin"] * d["cout"] + (d["cout"] if d["bias"] else 0)
         elif kind == "dw":
@@ -153,13 +160,13 @@ def count_params(classes=21, backbone="xception", alpha=1.0):
     return n
 
 
-def make_synthetic_weights(seed=1234, classes=21, backbone="xception", alpha=1.0):
+def make_synthetic_weights(seed=1234, classes=21, backbone="xception", alpha=1.0, decoder="full", class_prediction=True):
     """Seeded random parameters with variance-preserving scales so that activations stay O(1)
     through the 65+ layers (He-style std for kernels that follow a ReLU, 1/sqrt(fan_in)
     otherwise; BN statistics near identity; residual branches damped)."""
     rng = np.random.default_rng(seed)
     w = {}
-    inv = layer_inventory(classes, backbone, alpha)
+    inv = layer_inventory(classes, backbone, alpha, decoder, class_prediction)
     relu_before = set()        # conv layers whose input passed through a ReLU
     if backbone == "mobilenet":
         relu_before |= {"expanded_conv_depthwise", "expanded_conv_project"}

@@ -33,7 +33,11 @@ class OracleDeeplabV3Plus:
     """Xception backbone, OS=16 only (model.py:48-52: entry_block3_stride 2, middle rate 1,
     exit rates (1,2), atrous rates (6,12,18))."""
 
-    def __init__(self, weights: dict, classes=21, last_activation=None, backbone="xception", OS=16):
+    def __init__(self, weights: dict, classes=21, last_activation=None, backbone="xception", OS=16, decoder="full",
+                 first_upsample_size=(128, 128), class_prediction=True):
+        """decoder: "full" (Decoder, model.py:235-259) | "dcnn" (Decoder_only_DCNN, :261-280) | "aspp"
+        (Decoder_only_ASPP, :282-294); class_prediction=False: no logits layer (model.py:100-106)."""
+        self.decoder, self.first_upsample_size, self.class_prediction = decoder, tuple(first_upsample_size), class_prediction
         self.w = {k: torch.as_tensor(np.asarray(v, dtype=np.float32)) for k, v in weights.items()}
         self.classes = classes
         self.last_activation = last_activation
@@ -188,27 +192,36 @@ class OracleDeeplabV3Plus:
         x = self.xception_block(x, "exit_flow_block1", "conv", 1, rate=self.exit_block_rates[0])
         x = self.xception_block(x, "exit_flow_block2", None, 1, rate=self.exit_block_rates[1], depth_activation=True)
         stages["exit"] = x
-        # ASPP (model.py:192-233)
-        fh, fw = x.shape[2:]
-        pool = x.mean(dim=(2, 3), keepdim=True)
-        pool = F.relu(self.bn(self.conv(pool, "image_pooling"), "image_pooling_BN", 1e-5))
-        pool = self.resize(pool, (fh, fw))
-        b0 = F.relu(self.bn(self.conv(x, "aspp0"), "aspp0_BN", 1e-5))
-        b1 = self.sepconv_bn(x, "aspp1", rate=self.atrous_rates[0], depth_activation=True)
-        b2 = self.sepconv_bn(x, "aspp2", rate=self.atrous_rates[1], depth_activation=True)
-        b3 = self.sepconv_bn(x, "aspp3", rate=self.atrous_rates[2], depth_activation=True)
-        x = torch.cat([pool, b0, b1, b2, b3], dim=1)
-        x = F.relu(self.bn(self.conv(x, "concat_projection"), "concat_projection_BN", 1e-5))
-        stages["aspp"] = x
-        # decoder (model.py:235-259)
-        x = self.resize(x, skip.shape[2:])
-        dskip = F.relu(self.bn(self.conv(skip, "feature_projection0"), "feature_projection0_BN", 1e-5))
-        x = torch.cat([x, dskip], dim=1)
+        if self.decoder == "dcnn":
+            # Decoder_only_DCNN (model.py:261-280): projection of the encoder output, Resizing(first_upsample_size)
+            x = F.relu(self.bn(self.conv(x, "feature_projection0"), "feature_projection0_BN", 1e-5))
+            x = self.resize(x, self.first_upsample_size)
+        else:
+            # ASPP (model.py:192-233)
+            fh, fw = x.shape[2:]
+            pool = x.mean(dim=(2, 3), keepdim=True)
+            pool = F.relu(self.bn(self.conv(pool, "image_pooling"), "image_pooling_BN", 1e-5))
+            pool = self.resize(pool, (fh, fw))
+            b0 = F.relu(self.bn(self.conv(x, "aspp0"), "aspp0_BN", 1e-5))
+            b1 = self.sepconv_bn(x, "aspp1", rate=self.atrous_rates[0], depth_activation=True)
+            b2 = self.sepconv_bn(x, "aspp2", rate=self.atrous_rates[1], depth_activation=True)
+            b3 = self.sepconv_bn(x, "aspp3", rate=self.atrous_rates[2], depth_activation=True)
+            x = torch.cat([pool, b0, b1, b2, b3], dim=1)
+            x = F.relu(self.bn(self.conv(x, "concat_projection"), "concat_projection_BN", 1e-5))
+            stages["aspp"] = x
+            if self.decoder == "aspp":
+                x = self.resize(x, self.first_upsample_size)          # Decoder_only_ASPP (model.py:282-294)
+            else:
+                # decoder (model.py:235-259)
+                x = self.resize(x, skip.shape[2:])
+                dskip = F.relu(self.bn(self.conv(skip, "feature_projection0"), "feature_projection0_BN", 1e-5))
+                x = torch.cat([x, dskip], dim=1)
         x = self.sepconv_bn(x, "decoder_conv0", depth_activation=True, eps=1e-5)
         x = self.sepconv_bn(x, "decoder_conv1", depth_activation=True, eps=1e-5)
         stages["decoder"] = x
         # logits (model.py:296-306)
-        x = self.conv(x, "logits_semantic")
+        if self.class_prediction:
+            x = self.conv(x, "logits_semantic" if "logits_semantic/kernel" in self.w else "custom_logits_semantic")
         if final_upsample:
             x = self.resize(x, in_hw)
         if self.last_activation == "softmax":

@@ -53,6 +53,33 @@ def test_xception_os8_matches_oracle(dev, synthetic):
     np.testing.assert_allclose(got, ref, rtol=0, atol=2e-4 * np.abs(ref).max())
 
 
+@pytest.mark.parametrize("kw,name,shape", [
+    (dict(only_DCNN_output=True, first_upsample_size=(24, 40)), "DLV3Plus-xception-OS16-Only_DCNN_Output", (2, 24, 40, 21)),
+    (dict(only_ASPP_output=True, first_upsample_size=(32, 32)), "DLV3Plus-xception-OS16-Only_ASPP_Output", (2, 32, 32, 21)),
+    (dict(final_class_prediction=False), "DLV3Plus-xception-OS16-no_class_prediction", (2, 16, 16, 256)),
+    (dict(only_ASPP_output=True, first_upsample_size=(16, 16), final_class_prediction=False, final_upsample=True),
+     "DLV3Plus-xception-OS16-no_class_prediction", (2, 64, 64, 256)),
+])
+def test_modified_decoders_match_oracle(dev, kw, name, shape):
+    """build_model(only_DCNN_output / only_ASPP_output / first_upsample_size / final_class_prediction), model.py:64-118
+    and the decoders of :261-294, through the reference-shaped constructor; synthetic weights of the variant's inventory."""
+    from asr_amd import weights as W
+    from asr_amd.model import DeeplabV3Plus
+    rng = np.random.default_rng(29)
+    x = rng.random((2, 64, 64, 3), dtype=np.float32)
+    decoder = "dcnn" if kw.get("only_DCNN_output") else ("aspp" if kw.get("only_ASPP_output") else "full")
+    cp = kw.get("final_class_prediction", True)
+    weights = W.make_synthetic_weights(1234, 21, decoder=decoder, class_prediction=cp)
+    ref = OracleDeeplabV3Plus(weights, decoder=decoder, first_upsample_size=kw.get("first_upsample_size", (128, 128)),
+                              class_prediction=cp).forward(x, final_upsample=kw.get("final_upsample", False))
+    model = DeeplabV3Plus(input_shape=(64, 64, 3), classes=21, OS=16, synthetic_seed=1234).build_model(
+        **{"final_upsample": False, **kw})
+    assert model.name == name
+    got = model.predict(x, batch_size=2)
+    assert got.shape == ref.shape == shape
+    np.testing.assert_allclose(got, ref, rtol=0, atol=2e-4 * np.abs(ref).max())
+
+
 def test_final_upsample_matches_oracle(dev, synthetic):
     from asr_amd.model import DeeplabModel
     rng = np.random.default_rng(22)

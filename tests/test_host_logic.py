@@ -23,8 +23,15 @@ def test_deeplab_constructor_validation_matches_reference():
                       backbone="xception")
     with pytest.raises(ValueError, match="only_DCNN_output"):
         m.build_model(only_DCNN_output=True, only_ASPP_output=True)
-    with pytest.raises(NotImplementedError):
-        m.build_model(only_ASPP_output=True)
+    # the modified decoders change the layer inventory (model.py:261-294): 2048 -> 48 projection / no skip concat
+    from asr_amd import weights as W
+    shapes = {d: {n: i for k, n, i in W.layer_inventory(decoder=d)} for d in ("full", "dcnn", "aspp")}
+    assert shapes["full"]["feature_projection0"]["cin"] == 256 and shapes["full"]["decoder_conv0_depthwise"]["c"] == 304
+    assert shapes["dcnn"]["feature_projection0"]["cin"] == 2048 and shapes["dcnn"]["decoder_conv0_depthwise"]["c"] == 48
+    assert "feature_projection0" not in shapes["aspp"] and shapes["aspp"]["decoder_conv0_depthwise"]["c"] == 256
+    assert "logits_semantic" not in {n for _k, n, _i in W.layer_inventory(class_prediction=False)}
+    with pytest.raises(ValueError, match="decoder"):
+        W.layer_inventory(decoder="unet")
 
 
 def test_mobilenet_inventory_follows_the_reference_graph():
