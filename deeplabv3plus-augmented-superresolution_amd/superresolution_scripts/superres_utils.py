@@ -157,6 +157,9 @@ def check_validity(file, num_aug=100):
     return True
 
 
+check_hdf5_validity = check_validity          # the reference's name (superres_utils.py:108)
+
+
 def load_SR_data(filepath, num_aug=100, global_normalize=True):
     """Returns (class_masks [N,h,w,1], max_masks | None, angles, shifts, filename) as host arrays;
     argmax / slice_max masks are min-max normalised to [0,1] (superres_utils.py:183-206)."""

@@ -37,6 +37,30 @@ def _stack_copies(copies, device):
     return t.contiguous()
 
 
+def bilateral_tv(target_image, alpha=0.6, shift_factor=2):
+    """The reference's module-level prior (superresolution.py:8-23): sum over the 15 integer shifts p = (h, v), h in
+    [-s, s], v in [0, s], of alpha^(|h|+|v|) * || x - translate(x, p) ||_1 (zero fill).  target_image [1,H,W,1] / [H,W]
+    (host array or device tensor) -> Python float; evaluated by the solver's own prior kernel (sr_loss_prior_kernel)."""
+    import ctypes as C
+    dev = _lib.require_gpu()
+    t = target_image if isinstance(target_image, torch.Tensor) else torch.as_tensor(np.asarray(target_image, dtype=np.float32))
+    t = t.to(device=dev, dtype=torch.float32)
+    if t.dim() == 4:
+        if t.shape[0] != 1 or t.shape[-1] != 1:
+            raise ValueError(f"bilateral_tv expects [1,H,W,1] or [H,W], got {tuple(t.shape)}")
+        t = t[0, :, :, 0]
+    if t.dim() != 2:
+        raise ValueError(f"bilateral_tv expects [1,H,W,1] or [H,W], got {tuple(t.shape)}")
+    x = t.contiguous()[None]
+    H, W = x.shape[1:]
+    resid = torch.zeros(1, dtype=torch.float32, device=dev)                 # no data term: one zero residual
+    terms = torch.empty((1, 4), dtype=torch.float64, device=dev)
+    cfg = ops.sr_config(use_btv=True, btv_alpha=alpha, btv_shift=shift_factor)
+    ops.call("asr_sr_loss_terms_cfg_f64", ops.ptr(x), ops.ptr(resid), ops.ptr(terms, torch.float64), 1, 1, H, W, 1, 1,
+             C.byref(cfg), ops.stream_ptr())
+    return float(terms[0, 1].item())
+
+
 class Superresolution:
     def __init__(self, lambda_df, lambda_tv, lambda_L2, lambda_L1, num_iter=200, num_aug=100,
                  optimizer: Optimizer = None, feature_size=(64, 64), output_size=(512, 512), use_BTV=False,

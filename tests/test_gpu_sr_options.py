@@ -93,3 +93,17 @@ def test_copy_dropout_matches_oracle_and_freezes_its_mask(dev):
     # dropping copies changes the data term: not the result of the full stack
     full, _ = _pair("adam", iters=iters, n=n, H=H, h=h, amsgrad=True)[0].augmented_superresolution(y[0][..., None], angs[0], shs[0])
     assert np.abs(full - outs[0]).max() > 1e-4
+
+
+def test_module_level_bilateral_tv_matches_oracle(dev):
+    """superresolution.py:8-23 as a free function (odd sizes, other alpha / window than the solver's defaults)."""
+    from asr_amd.superresolution_scripts.superresolution import bilateral_tv
+    from asr_amd.superresolution_scripts import superres_utils as su
+    rng = np.random.default_rng(77)
+    img = rng.random((1, 37, 53, 1), dtype=np.float32)
+    for alpha, s in ((0.6, 2), (0.8, 3), (0.5, 1)):
+        ref = o_sr.bilateral_tv(torch.from_numpy(img), alpha=alpha, shift_factor=s)
+        got = bilateral_tv(img, alpha=alpha, shift_factor=s)
+        assert abs(got - ref) <= 1e-6 * ref, (alpha, s, got, ref)
+    assert bilateral_tv(img[0, :, :, 0]) == bilateral_tv(img)
+    assert su.check_hdf5_validity is su.check_validity
