@@ -203,6 +203,185 @@ __global__ __launch_bounds__(256) void conv3x3_stem_mfma_kernel(const float* __r
     }
 }
 
+// ---- entry_flow_conv1_1 + entry_flow_conv1_2 in one kernel (asr_entry_stem_f16x3) ---------------------------------
+// y = relu(conv3x3_same(relu(conv3x3_s2_same(x, w1) + b1), w2) + b2): 3 -> 32 channels at stride 2, then 32 -> 64.
+// A persistent workgroup (8 waves) owns 16 x 16 output pixels at a time:
+//   stage 1  the 18 x 18 conv1_1 outputs under the tile (halo 1; positions outside the map are conv1_2's zero padding)
+//            are computed on the matrix cores exactly like conv3x3_stem_mfma_kernel, but with the MFMA operands swapped
+//            (weights as A) so that a lane holds one pixel and 4 consecutive channels per register quad, and are written
+//            to LDS already split into hi/lo f16: one 128-byte line per pixel [hi c0-31 | lo c0-31] in 16-byte slots,
+//            slot XOR (pixel >> 1) & 7;
+//   stage 2  conv1_2 as an implicit GEMM whose A fragments come straight from that LDS image (tap (ky, kx) = the line of
+//            pixel (y + ky, x + kx)) and whose weights (9 taps x 32 x 64, hi + lo: 72 KB) stay resident in LDS for the
+//            kernel's lifetime: 108 MFMAs per wave and tile, no global A traffic at all.
+// The 32-channel intermediate (839 MB per 100 copies, written once and re-read nine times through L2 by the implicit
+// GEMM of the two-kernel form) never leaves the CU.
+constexpr int ES_T = 16, ES_H = ES_T + 2, ES_NPIX = ES_H * ES_H, ES_GROUPS = (ES_NPIX + 31) / 32;
+constexpr int ES_T1_BYTES = ES_NPIX * 128, ES_B_BYTES = 36 * 64 * 16, ES_LDS_BYTES = ES_T1_BYTES + 2 * ES_B_BYTES;   // 112.5 KB
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(512) void entry_stem_fused_kernel(const float* __restrict__ x, const float* __restrict__ w1,
+                                                               const float* __restrict__ b1, const _Float16* __restrict__ w2p,
+                                                               const float* __restrict__ b2, float* __restrict__ y, int batch,
+                                                               int h_in, int w_in, int h1, int w1d, int ldx, int ldy, int npad2) {
+    extern __shared__ __attribute__((aligned(16))) char es_lds[];
+    char* const T1 = es_lds;
+    char* const Bh = es_lds + ES_T1_BYTES;
+    char* const Bl = Bh + ES_B_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l32 = lane & 31, hh = lane >> 5;
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    {   // conv1_2's weights: packed planes [36 octets][npad2][8 halfs] (hi, then lo) -> LDS [36][64][8]
+        const long long plane = (long long)288 * npad2;
+        for (int i = tid; i < 36 * 64; i += 512) {
+            const int oct = i >> 6, col = i & 63;
+            const _Float16* src = w2p + ((long long)oct * npad2 + col) * 8;
+            *reinterpret_cast<u32x4*>(Bh + i * 16) = *reinterpret_cast<const u32x4*>(src);
+            *reinterpret_cast<u32x4*>(Bl + i * 16) = *reinterpret_cast<const u32x4*>(src + plane);
+        }
+    }
+    // stage-1 constants: k slot (s, j) of this lane half = input element e = 16 s + 8 hh + j = (ky * 3 + kx) * 3 + ci
+    f16x8 wh[2], wl[2];
+    int off[16], kyx[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int e = 16 * (k >> 3) + 8 * hh + (k & 7);
+        const bool ok = e < 27;
+        const int ec = ok ? e : 0;
+        const int tap = ec / 3, ci = ec - tap * 3, ky = tap / 3, kx = tap - ky * 3;
+        off[k] = (ky * w_in + kx) * ldx + ci;
+        kyx[k] = ky | (kx << 2) | ((int)ok << 4);
+        const float wv = ok ? w1[ec * 32 + l32] : 0.0f;
+        const _Float16 hi = (_Float16)wv;
+        wh[k >> 3][k & 7] = hi;
+        wl[k >> 3][k & 7] = (_Float16)(wv - (float)hi);
+    }
+    float b1v[16];                                            // bias of the channel each accumulator register holds
+#pragma unroll
+    for (int e = 0; e < 16; ++e) b1v[e] = b1[(e & 3) + 8 * (e >> 2) + 4 * hh];
+    const float b2v0 = b2[l32], b2v1 = b2[32 + l32];
+
+    const int tiles_x = (w1d + ES_T - 1) / ES_T, tiles_y = (h1 + ES_T - 1) / ES_T;
+    const long long total = (long long)batch * tiles_y * tiles_x;
+
+    // Stage 1 of one 32-pixel group: gather() issues the lane's 16 image loads, finish() turns them into conv1_1 lines.
+    // (Software-pipelining the two stages over the tiles -- the next tile's gather in flight under stage 2, a second
+    // LDS image -- measured no faster: 982 vs 938 us; the tile time is set by stage 2's MFMAs and the 64 KB of stores.)
+    struct Gathered {
+        float a[16];
+        int t;
+        bool in_map;
+    };
+    auto gather = [&](long long tile, int g) -> Gathered {
+        Gathered r;
+        const int tx0 = (int)(tile % tiles_x) * ES_T;
+        const long long tt = tile / tiles_x;
+        const int ty0 = (int)(tt % tiles_y) * ES_T;
+        const float* xin = x + (tt / tiles_y) * h_in * w_in * ldx;
+        r.t = 32 * g + l32;
+        const int tyy = r.t / ES_H, txx = r.t - tyy * ES_H;
+        const int oy1 = ty0 - 1 + tyy, ox1 = tx0 - 1 + txx;
+        r.in_map = r.t < ES_NPIX && oy1 >= 0 && oy1 < h1 && ox1 >= 0 && ox1 < w1d;
+        const int iy0 = 2 * oy1, ix0 = 2 * ox1;                // 'same' at stride 2 on an even input: pad bottom / right only
+        const long long org = ((long long)iy0 * w_in + ix0) * ldx;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int iy = iy0 + (kyx[k] & 3), ix = ix0 + ((kyx[k] >> 2) & 3);
+            const bool in = (kyx[k] & 16) && r.in_map && iy < h_in && ix < w_in;
+            const float v = xin[in ? org + off[k] : 0];
+            r.a[k] = in ? v : 0.0f;
+        }
+        return r;
+    };
+    auto finish = [&](const Gathered& r, char* T1) {
+        f16x8 xh[2], xl[2];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const _Float16 hi = (_Float16)r.a[k];
+            xh[k >> 3][k & 7] = hi;
+            xl[k >> 3][k & 7] = (_Float16)(r.a[k] - (float)hi);
+        }
+        f32x16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {                          // D[channel][pixel]: weights as the A operand
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[s], xl[s], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[s], xh[s], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[s], xh[s], acc, 0, 0, 0);
+        }
+        if (r.t < ES_NPIX) {
+            char* const line = T1 + r.t * 128;
+            const int swz = (r.t >> 1) & 7;
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {                   // registers 4 g4 .. 4 g4 + 3 = channels 8 g4 + 4 hh + 0..3
+                f16x4 hi, lo;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float v = r.in_map ? fmaxf(acc[4 * g4 + i] + b1v[4 * g4 + i], 0.0f) : 0.0f;
+                    const _Float16 h = (_Float16)v;
+                    hi[i] = h;
+                    lo[i] = (_Float16)(v - (float)h);
+                }
+                *reinterpret_cast<f16x4*>(line + ((g4 ^ swz) << 4) + hh * 8) = hi;
+                *reinterpret_cast<f16x4*>(line + (((4 + g4) ^ swz) << 4) + hh * 8) = lo;
+            }
+        }
+    };
+    const bool two_groups = wave + 8 < ES_GROUPS;              // waves 0..2 own a second group of the 11
+
+    for (long long tile = blockIdx.x; tile < total; tile += gridDim.x) {
+        __syncthreads();                                       // the previous tile's stage 2 is done with the LDS image
+        // ---- stage 1: conv1_1 (+ bias, ReLU) of the 18 x 18 halo tile -> split-f16 lines in LDS ----
+        finish(gather(tile, wave), T1);
+        if (two_groups) finish(gather(tile, wave + 8), T1);
+        __syncthreads();
+        const int tx0 = (int)(tile % tiles_x) * ES_T;
+        const long long tt = tile / tiles_x;
+        const int ty0 = (int)(tt % tiles_y) * ES_T;
+        const long long b = tt / tiles_y;
+        // ---- stage 2: conv1_2 from the LDS image; this wave's 32 output pixels = 2 rows x 16 columns ----
+        const int o = 32 * wave + l32, yy = o >> 4, xx = o & 15;
+        f32x16 acc2[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc2[j][e] = 0.0f;
+#pragma unroll 3                                               // fully unrolled, the hoisted LDS reads spill
+        for (int tap = 0; tap < 9; ++tap) {
+            const int ky = (tap * 11) >> 5;                    // tap / 3 for tap < 9
+            const int tp = (yy + ky) * ES_H + xx + (tap - 3 * ky);
+            const char* const line = T1 + tp * 128;
+            const int swz = (tp >> 1) & 7;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const int oct = 2 * kk + hh;
+                const f16x8 ah = *reinterpret_cast<const f16x8*>(line + ((oct ^ swz) << 4));
+                const f16x8 al = *reinterpret_cast<const f16x8*>(line + (((4 + oct) ^ swz) << 4));
+                const int og = tap * 4 + oct;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const f16x8 bh = *reinterpret_cast<const f16x8*>(Bh + (og * 64 + j * 32 + l32) * 16);
+                    const f16x8 bl = *reinterpret_cast<const f16x8*>(Bl + (og * 64 + j * 32 + l32) * 16);
+                    acc2[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc2[j], 0, 0, 0);
+                    acc2[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc2[j], 0, 0, 0);
+                    acc2[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc2[j], 0, 0, 0);
+                }
+            }
+        }
+        float* const ybase = y + (b * h1 * w1d) * ldy + l32;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int r = 32 * wave + (e & 3) + 8 * (e >> 2) + 4 * hh;       // pixel of accumulator row e
+            const int oy = ty0 + (r >> 4), ox = tx0 + (r & 15);
+            if (oy < h1 && ox < w1d) {
+                float* const q = ybase + ((long long)oy * w1d + ox) * ldy;
+                q[0] = fmaxf(acc2[0][e] + b2v0, 0.0f);
+                q[32] = fmaxf(acc2[1][e] + b2v1, 0.0f);
+            }
+        }
+    }
+}
+
 // ---- global average pool: block = 64 channel-quads x 4 pixel groups ----------------------------
 __global__ __launch_bounds__(256) void gap_kernel(const float* __restrict__ x, float* __restrict__ y, int hw, int c, int ldx) {
     __shared__ f32x4 part[4][64];
@@ -301,6 +480,32 @@ extern "C" int asr_conv3x3_stem_f16x3(const float* x, const float* w, const floa
     const long long waves = (long long)batch * h_out * asr_cdiv(w_out, 32);
     hipLaunchKernelGGL(conv3x3_stem_mfma_kernel, dim3(cap_grid(waves * 64)), dim3(256), 0, asr_stream(stream), x, w, bias, y,
                        batch, h_in, w_in, stride, pad_top, pad_left, h_out, w_out, ldx, ldy, relu);
+    ASR_LAUNCH_CHECK();
+    return ASR_OK;
+}
+
+extern "C" int asr_entry_stem_f16x3(const float* x, const float* w1, const float* b1, const void* w2_packed, const float* b2,
+                                    float* y, int batch, int h_in, int w_in, int ldx, int ldy, asr_stream_t stream) {
+    ASR_REQUIRE(x && w1 && b1 && w2_packed && b2 && y, "asr_entry_stem_f16x3: null pointer");
+    ASR_REQUIRE(batch > 0 && h_in > 0 && w_in > 0 && ldx >= 3 && ldy >= 64, "asr_entry_stem_f16x3: bad geometry");
+    ASR_UNSUPPORTED((h_in | w_in) & 1, "asr_entry_stem_f16x3: even input size required (got %dx%d)", h_in, w_in);
+    ASR_UNSUPPORTED((long long)h_in * w_in * ldx > 0x7fffffffLL, "asr_entry_stem_f16x3: image too large");
+    ASR_UNSUPPORTED(reinterpret_cast<uintptr_t>(w2_packed) & 15, "asr_entry_stem_f16x3: w2_packed must be 16-byte aligned");
+    const int h1 = h_in / 2, w1d = w_in / 2;
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        ASR_HIP_CHECK(hipGetDevice(&dev));
+        ASR_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+        cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        ASR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(entry_stem_fused_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, ES_LDS_BYTES));
+    }
+    const long long tiles = (long long)batch * asr_cdiv(h1, ES_T) * asr_cdiv(w1d, ES_T);
+    const int grid = (int)(tiles < cus ? tiles : cus);
+    hipLaunchKernelGGL(entry_stem_fused_kernel, dim3(grid), dim3(512), ES_LDS_BYTES, asr_stream(stream), x, w1, b1,
+                       reinterpret_cast<const _Float16*>(w2_packed), b2, y, batch, h_in, w_in, h1, w1d, ldx, ldy, 128);
     ASR_LAUNCH_CHECK();
     return ASR_OK;
 }

@@ -350,18 +350,24 @@ class DeeplabEngine:
             return dict(steps=steps, outs=outs, pool=pool, x_in=x_in, logits=logits, pool_bytes=pool.total_bytes,
                         out_shape=(B, fh, fw, self.classes))
         # ---- entry flow (model.py:149-170) ----
-        a1 = new((B, h1, w1, 32))
-        p = self.p["entry_flow_conv1_1"]
-        add("asr_conv3x3_stem_f16x3" if self.precision == "f16x3" else "asr_conv3x3_direct_f32",
-            (x_in.ptr, p["w"].data_ptr(), p["b"].data_ptr(), a1.ptr, B, H, Wd, 3, 32, 2, pt, pl,
-                                       h1, w1, 3, 32, 1), "conv", 2.0 * B * h1 * w1 * 27 * 32,
-            4.0 * (B * H * Wd * 3 + B * h1 * w1 * 32))
+        p1, p2 = self.p["entry_flow_conv1_1"], self.p["entry_flow_conv1_2"]
         a2 = new((B, h1, w1, 64))
-        p = self.p["entry_flow_conv1_2"]
-        add(p["fn"], (a1.ptr, p["w"].data_ptr(), p["b"].data_ptr(), a2.ptr, B, h1, w1, 32, 64, 1, 1, 1, h1,
-                      w1, 32, 64, 1), "conv", 2.0 * B * h1 * w1 * 288 * 64,
-            4.0 * (B * h1 * w1 * 96))
-        release(a1)
+        if (self.precision == "f16x3" and p2["fn"].endswith("f16x3") and H % 2 == 0 and Wd % 2 == 0
+                and not os.environ.get("ASR_NO_FUSED_STEM")):
+            # conv1_1 + conv1_2 in one kernel: the 32-channel intermediate stays in LDS
+            add("asr_entry_stem_f16x3", (x_in.ptr, p1["w"].data_ptr(), p1["b"].data_ptr(), p2["w"].data_ptr(), p2["b"].data_ptr(),
+                                         a2.ptr, B, H, Wd, 3, a2.ld), "conv", 2.0 * B * h1 * w1 * (27 * 32 + 288 * 64),
+                4.0 * (B * H * Wd * 3 + B * h1 * w1 * 64), label="entry_flow_conv1_1+conv1_2 fused", out=a2)
+        else:
+            a1 = new((B, h1, w1, 32))
+            add("asr_conv3x3_stem_f16x3" if self.precision == "f16x3" else "asr_conv3x3_direct_f32",
+                (x_in.ptr, p1["w"].data_ptr(), p1["b"].data_ptr(), a1.ptr, B, H, Wd, 3, 32, 2, pt, pl,
+                 h1, w1, 3, 32, 1), "conv", 2.0 * B * h1 * w1 * 27 * 32,
+                4.0 * (B * H * Wd * 3 + B * h1 * w1 * 32))
+            add(p2["fn"], (a1.ptr, p2["w"].data_ptr(), p2["b"].data_ptr(), a2.ptr, B, h1, w1, 32, 64, 1, 1, 1, h1,
+                           w1, 32, 64, 1), "conv", 2.0 * B * h1 * w1 * 288 * 64,
+                4.0 * (B * h1 * w1 * 96))
+            release(a1)
         x = block(a2, "entry_flow_block1", "conv", 2, 1, False)
         x, skip = block(x, "entry_flow_block2", "conv", 2, 1, False, return_skip=True)
         x = block(x, "entry_flow_block3", "conv", self.entry_block3_stride, 1, False)

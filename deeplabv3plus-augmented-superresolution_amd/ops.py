@@ -374,6 +374,17 @@ def conv3x3_direct(x, w_hwio, bias, stride, pad_top, pad_left, out_hw, relu=Fals
     return y
 
 
+def entry_stem_fused(x, w1_hwio, b1, w2_packed16, b2):
+    """relu(conv3x3(relu(conv3x3_s2(x, w1) + b1), w2) + b2), 3 -> 32 -> 64 channels, in one kernel (even input sizes);
+    w2_packed16 = pack_pw_weights_f16x3 of the [288, 64] matrix."""
+    b, h, w, c = x.shape
+    if c != 3 or tuple(w1_hwio.shape) != (3, 3, 3, 32):
+        raise AsrError("entry_stem_fused: x [B,H,W,3] and w1 [3,3,3,32] expected")
+    y = torch.empty((b, h // 2, w // 2, 64), dtype=f32, device=x.device)
+    call("asr_entry_stem_f16x3", ptr(x), ptr(w1_hwio), ptr(b1), ptr(w2_packed16), ptr(b2), ptr(y), b, h, w, 3, 64, stream_ptr())
+    return y
+
+
 def dwconv3x3_split(x, w_33c, bias, stride=1, rate=1, pre_relu=False, post_relu=0):
     """Depthwise 3x3 ('same', or the explicit symmetric pad of the stride-2 sepconvs) whose output is written as
     split-f16 chunks for pwconv_presplit.  Returns (buffer [B*Ho*Wo, chunks, 32] float32-typed storage, (B, Ho, Wo), chunks)."""

@@ -300,6 +300,13 @@ int asr_conv3x3_stem_f16x3(const float* x, const float* w, const float* bias, fl
                            int cin, int cout, int stride, int pad_top, int pad_left, int h_out, int w_out, int ldx,
                            int ldy, int relu, asr_stream_t stream);
 
+/* entry_flow_conv1_1 + BN + ReLU + entry_flow_conv1_2 + BN + ReLU (model.py:150-155) in one kernel on split-f16 MFMA:
+ * x [batch,h_in,w_in,3] (even sizes) -> y [batch,h_in/2,w_in/2,64].  w1 [3,3,3,32] HWIO and b1 [32], b2 [64] with the BNs
+ * folded; w2_packed = asr_pwconv_pack_weights_f16x3 of the [288, 64] matrix (rows (ky, kx, cin)).  The 32-channel
+ * intermediate stays in LDS. */
+int asr_entry_stem_f16x3(const float* x, const float* w1, const float* b1, const void* w2_packed, const float* b2, float* y,
+                         int batch, int h_in, int w_in, int ldx, int ldy, asr_stream_t stream);
+
 /* DepthwiseConv2D 3x3 (+ ZeroPadding2D, folded BN, ReLU before and/or after): the depthwise half
  * of _SepConv_BN, model.py:478-495, and of _inverted_res_block, model.py:442-449 (post_relu = 2: ReLU6).
  * w [3,3,c] with the BN scale folded, bias [c].

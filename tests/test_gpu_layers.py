@@ -156,6 +156,30 @@ def test_conv3x3_direct_same_padding_stride2(dev, f16x3):
     assert np.count_nonzero(np.abs(g).sum(-1)) == 1 and np.allclose(g[0, 3, 3], k[1, 1, 0], rtol=1e-6, atol=1e-7)
 
 
+@pytest.mark.parametrize("b,h,w_", [(2, 64, 96), (1, 70, 90), (3, 32, 32)])
+def test_entry_stem_fused_matches_the_two_kernels(dev, b, h, w_):
+    """conv1_1 + conv1_2 in one kernel (intermediate in LDS) against the stem kernel followed by the implicit-GEMM conv,
+    and against torch f32: ragged 16 x 16 tiles, map borders (conv1_2's zero padding around the conv1_1 map)."""
+    from asr_amd import ops
+    rng = np.random.default_rng(101)
+    x = _rand(rng, b, h, w_, 3)
+    k1 = _rand(rng, 3, 3, 3, 32, scale=0.3)
+    b1 = _rand(rng, 32, scale=0.2)
+    k2 = _rand(rng, 3, 3, 32, 64, scale=(2.0 / 288) ** 0.5)
+    b2 = _rand(rng, 64, scale=0.2)
+    xd = ops.to_device(x)
+    w2p = ops.pack_pw_weights_f16x3(ops.to_device(k2.reshape(288, 64)))
+    got = ops.entry_stem_fused(xd, ops.to_device(k1), ops.to_device(b1), w2p, ops.to_device(b2)).cpu().numpy()
+    mid = ops.conv3x3_direct(xd, ops.to_device(k1), ops.to_device(b1), 2, 0, 0, (h // 2, w_ // 2), relu=True, f16x3=True)
+    two = ops.conv3x3_mfma(mid, w2p, ops.to_device(b2), 64, relu=True, f16x3=True).cpu().numpy()
+    xt = F.pad(torch.from_numpy(x).permute(0, 3, 1, 2), (0, 1, 0, 1))
+    m = F.conv2d(xt, torch.from_numpy(k1).permute(3, 2, 0, 1), torch.from_numpy(b1), stride=2).relu()
+    ref = F.conv2d(m, torch.from_numpy(k2).permute(3, 2, 0, 1), torch.from_numpy(b2), padding=1).relu().permute(0, 2, 3, 1).numpy()
+    assert got.shape == ref.shape == (b, h // 2, w_ // 2, 64)
+    np.testing.assert_allclose(got, two, rtol=0, atol=2e-5)
+    np.testing.assert_allclose(got, ref, rtol=0, atol=5e-5)
+
+
 def _dw_ref(x, k, bias, stride, rate, pad, pre, post):
     xt = torch.from_numpy(x).permute(0, 3, 1, 2)
     if pre:
