@@ -86,6 +86,7 @@ SIGNATURES = {
     "asr_conv3x3_direct_f32": (_i, [_vp, _vp, _vp, _vp] + [_i] * 13 + [_vp]),
     "asr_conv3x3_stem_f16x3": (_i, [_vp, _vp, _vp, _vp] + [_i] * 13 + [_vp]),
     "asr_entry_stem_f16x3": (_i, [_vp] * 6 + [_i] * 5 + [_vp]),
+    "asr_sepconv_fused_f16x3": (_i, [_vp] * 6 + [_i] * 10 + [_vp]),
     "asr_dwconv3x3_nhwc_f32": (_i, [_vp, _vp, _vp, _vp] + [_i] * 15 + [_vp]),
     "asr_aspp_dwconv3_nhwc_f32": (_i, [_vp] * 6 + [_i] * 11 + [_vp]),
     "asr_aspp_dwconv3_nhwc_split_f16": (_i, [_vp] * 6 + [_i] * 11 + [_vp]),

@@ -24,6 +24,7 @@ SOURCES = [
     ("gemm.hip", []),
     ("dwconv.hip", []),
     ("layers.hip", []),
+    ("sepconv.hip", []),
 ]
 HEADERS = ["asr_common.h", "asr_warp_device.h", os.path.join("..", "..", "include", "asr_hip.h")]
 COMMON = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",

@@ -258,6 +258,20 @@ class DeeplabEngine:
             split_ok = (pp.get("fn", "").endswith("f16x3") and (-(-pp["n"] // 128) * 128) % 256 == 0 and not pw_kw.get("out_off")
                         and pw_kw.get("sub", 1) == 1 and ((stride == 1 and rate in (1, 2)) or (stride == 2 and rate == 1))
                         and ho % srows == 0 and c % 8 == 0 and b <= 65535 and b * ho * wo >= 256 and not os.environ.get("ASR_NO_PRESPLIT"))
+            fused_ok = (pp.get("fn", "").endswith("f16x3") and stride == 1 and rate == 1 and c in (64, 128) and pp["n"] == 128
+                        and not pw_kw.get("out_off") and pw_kw.get("sub", 1) == 1 and pw_kw.get("res") is None
+                        and pp["b"] is not None and x.ld % 4 == 0 and not os.environ.get("ASR_NO_FUSED_SEPCONV"))
+            if fused_ok:
+                # both halves in one kernel: the depthwise output lives in LDS only (entry-flow block 1 at 256 x 256)
+                out = pw_kw.get("out")
+                if out is None:
+                    out = new((b, ho, wo, pp["n"]), pad=pw_kw.get("pad_out", True))
+                add("asr_sepconv_fused_f16x3",
+                    (x.ptr, pd["w"].data_ptr(), pd["b"].data_ptr(), pp["w"].data_ptr(), pp["b"].data_ptr(), out.ptr, b, h, w, c,
+                     pp["n"], x.ld, out.ld, int(not depth_act), int(depth_act), int(depth_act)),
+                    "dw", 18.0 * b * h * w * c + 2.0 * b * h * w * c * pp["n"], 4.0 * (b * h * w * c + b * h * w * pp["n"]),
+                    label=f"{prefix} fused dw+pw {h}x{w}x{c}->{pp['n']}", out=out)
+                return out
             if split_ok:
                 # depthwise writes the pointwise GEMM's A operand directly as split-f16 chunks; the GEMM takes both operands
                 # by LDS-DMA on a 256 x 256 tile (bit-identical to the f32 hand-off, see include/asr_hip.h)

@@ -385,6 +385,15 @@ def entry_stem_fused(x, w1_hwio, b1, w2_packed16, b2):
     return y
 
 
+def sepconv_fused(x, w_33c, bias_dw, w_packed16, bias_pw, cout, pre_relu=False, dw_relu=False, out_relu=False):
+    """A whole separable conv (depthwise 3x3 stride 1 + pointwise, cin in {64, 128} -> 128) in one kernel."""
+    b, h, w, c = x.shape
+    y = torch.empty((b, h, w, cout), dtype=f32, device=x.device)
+    call("asr_sepconv_fused_f16x3", ptr(x), ptr(w_33c), ptr(bias_dw), ptr(w_packed16), ptr(bias_pw), ptr(y), b, h, w, c, cout, c,
+         cout, int(pre_relu), int(dw_relu), int(out_relu), stream_ptr())
+    return y
+
+
 def dwconv3x3_split(x, w_33c, bias, stride=1, rate=1, pre_relu=False, post_relu=0):
     """Depthwise 3x3 ('same', or the explicit symmetric pad of the stride-2 sepconvs) whose output is written as
     split-f16 chunks for pwconv_presplit.  Returns (buffer [B*Ho*Wo, chunks, 32] float32-typed storage, (B, Ho, Wo), chunks)."""

@@ -307,6 +307,15 @@ int asr_conv3x3_stem_f16x3(const float* x, const float* w, const float* bias, fl
 int asr_entry_stem_f16x3(const float* x, const float* w1, const float* b1, const void* w2_packed, const float* b2, float* y,
                          int batch, int h_in, int w_in, int ldx, int ldy, asr_stream_t stream);
 
+/* A whole _SepConv_BN (model.py:463-508) in one kernel for the high-resolution entry-flow layers: [ReLU ->] depthwise
+ * 3x3 (stride 1, rate 1, 'same') + BN [-> ReLU] -> pointwise 1x1 + BN [-> ReLU]; cin in {64, 128}, cout = 128.  The
+ * depthwise output goes to LDS as split-f16 lines and is consumed there by the MFMA GEMM (weights resident in LDS);
+ * bit-identical to asr_dwconv3x3_nhwc_f32 followed by asr_pwconv_mfma_f16x3.  w_dw [3,3,cin], w_pw_packed from
+ * asr_pwconv_pack_weights_f16x3 of the [cin, cout] matrix. */
+int asr_sepconv_fused_f16x3(const float* x, const float* w_dw, const float* bias_dw, const void* w_pw_packed,
+                            const float* bias_pw, float* y, int batch, int h, int w, int cin, int cout, int ldx, int ldy,
+                            int pre_relu, int dw_relu, int out_relu, asr_stream_t stream);
+
 /* DepthwiseConv2D 3x3 (+ ZeroPadding2D, folded BN, ReLU before and/or after): the depthwise half
  * of _SepConv_BN, model.py:478-495, and of _inverted_res_block, model.py:442-449 (post_relu = 2: ReLU6).
  * w [3,3,c] with the BN scale folded, bias [c].

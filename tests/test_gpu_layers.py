@@ -180,6 +180,28 @@ def test_entry_stem_fused_matches_the_two_kernels(dev, b, h, w_):
     np.testing.assert_allclose(got, ref, rtol=0, atol=5e-5)
 
 
+@pytest.mark.parametrize("c,b,h,w_,depth_act", [(128, 2, 24, 40, False), (64, 2, 17, 30, False), (128, 1, 8, 14, True),
+                                                 (64, 3, 33, 15, True)])
+def test_sepconv_fused_is_bit_identical_to_the_two_kernels(dev, c, b, h, w_, depth_act):
+    """depthwise -> LDS (split f16) -> MFMA GEMM in one kernel against asr_dwconv3x3_nhwc_f32 + asr_pwconv_mfma_f16x3:
+    same depthwise arithmetic, same MFMA sequence per accumulator -> bitwise equal; ragged 8 x 14 tiles and image borders."""
+    from asr_amd import ops
+    rng = np.random.default_rng(303)
+    n = 128
+    x = ops.to_device(_rand(rng, b, h, w_, c))
+    wd = ops.to_device(_rand(rng, 3, 3, c, scale=0.3))
+    bd = ops.to_device(_rand(rng, c, scale=0.1))
+    wk = ops.to_device(_rand(rng, c, n, scale=(1.0 / c) ** 0.5))
+    bk = ops.to_device(_rand(rng, n, scale=0.1))
+    w16 = ops.pack_pw_weights_f16x3(wk)
+    ref_dw = ops.dwconv3x3(x, wd, bd, stride=1, rate=1, out_hw=(h, w_), pre_relu=not depth_act, post_relu=depth_act)
+    m = b * h * w_
+    ref = ops.pwconv(ref_dw.reshape(m, c), w16, bk, c, n, relu=depth_act, f16x3=True).reshape(b, h, w_, n)
+    got = ops.sepconv_fused(x, wd, bd, w16, bk, n, pre_relu=not depth_act, dw_relu=depth_act, out_relu=depth_act)
+    assert got.shape == ref.shape
+    assert torch.equal(got, ref), float((got - ref).abs().max())
+
+
 def _dw_ref(x, k, bias, stride, rate, pad, pre, post):
     xt = torch.from_numpy(x).permute(0, 3, 1, 2)
     if pre:
