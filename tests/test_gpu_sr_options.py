@@ -105,5 +105,6 @@ def test_module_level_bilateral_tv_matches_oracle(dev):
         ref = o_sr.bilateral_tv(torch.from_numpy(img), alpha=alpha, shift_factor=s)
         got = bilateral_tv(img, alpha=alpha, shift_factor=s)
         assert abs(got - ref) <= 1e-6 * ref, (alpha, s, got, ref)
-    assert bilateral_tv(img[0, :, :, 0]) == bilateral_tv(img)
+    a, b2 = bilateral_tv(img[0, :, :, 0]), bilateral_tv(img)      # float64 atomics: the summation order is not fixed
+    assert abs(a - b2) <= 1e-12 * abs(b2)
     assert su.check_hdf5_validity is su.check_validity
