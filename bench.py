@@ -320,6 +320,16 @@ def main():
                 "traffic_note": "launch-weighted mean HBM bytes of the dw_stream_full_kernel launches (PMC, as above)",
                 "launches": dl, "avg_launch_ms": round(dms / dl, 4),
             }
+        if "sepconv" in prof:
+            sms, _sfl, sby, sl = prof["sepconv"]
+            gbs = sby / (sms * 1e-3) / 1e9
+            out["roofline_fused_sepconv"] = {
+                "kernel": "sepconv_fused_kernel (asr_sepconv_fused_f16x3: depthwise -> LDS -> MFMA pointwise, entry-flow block 1)",
+                "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                "traffic": pmc_lookup("_ZN12_GLOBAL__N_120sepconv_fused_kernel"), "algorithmic_bytes_per_launch": round(sby / sl),
+                "traffic_note": "algorithmic bytes = layer input + layer output only (the depthwise tensor stays in LDS); PMC as above",
+                "launches": sl, "avg_launch_ms": round(sms / sl, 4),
+            }
         out["kernel_time_ms_per_step"] = {k: round(v[0], 3) for k, v in prof.items() if not k.startswith("_")}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(weights)

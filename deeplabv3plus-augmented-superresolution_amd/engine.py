@@ -269,7 +269,7 @@ class DeeplabEngine:
                 add("asr_sepconv_fused_f16x3",
                     (x.ptr, pd["w"].data_ptr(), pd["b"].data_ptr(), pp["w"].data_ptr(), pp["b"].data_ptr(), out.ptr, b, h, w, c,
                      pp["n"], x.ld, out.ld, int(not depth_act), int(depth_act), int(depth_act)),
-                    "dw", 18.0 * b * h * w * c + 2.0 * b * h * w * c * pp["n"], 4.0 * (b * h * w * c + b * h * w * pp["n"]),
+                    "sepconv", 18.0 * b * h * w * c + 2.0 * b * h * w * c * pp["n"], 4.0 * (b * h * w * c + b * h * w * pp["n"]),
                     label=f"{prefix} fused dw+pw {h}x{w}x{c}->{pp['n']}", out=out)
                 return out
             if split_ok:
