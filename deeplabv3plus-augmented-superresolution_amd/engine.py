@@ -258,7 +258,10 @@ class DeeplabEngine:
             split_ok = (pp.get("fn", "").endswith("f16x3") and (-(-pp["n"] // 128) * 128) % 256 == 0 and not pw_kw.get("out_off")
                         and pw_kw.get("sub", 1) == 1 and ((stride == 1 and rate in (1, 2)) or (stride == 2 and rate == 1))
                         and ho % srows == 0 and c % 8 == 0 and b <= 65535 and b * ho * wo >= 256 and not os.environ.get("ASR_NO_PRESPLIT"))
-            fused_ok = (pp.get("fn", "").endswith("f16x3") and stride == 1 and rate == 1 and c in (64, 128) and pp["n"] == 128
+            fused_ok = (pp.get("fn", "").endswith("f16x3") and stride == 1 and rate == 1
+                        and ((c in (64, 128) and pp["n"] == 128)
+                             # the 256-output streaming form measures equal to the two-kernel form: opt-in
+                             or (pp["n"] == 256 and c % 16 == 0 and os.environ.get("ASR_FUSED_SEPCONV256") == "1"))
                         and not pw_kw.get("out_off") and pw_kw.get("sub", 1) == 1 and pw_kw.get("res") is None
                         and pp["b"] is not None and x.ld % 4 == 0 and not os.environ.get("ASR_NO_FUSED_SEPCONV"))
             if fused_ok:

@@ -386,7 +386,8 @@ def entry_stem_fused(x, w1_hwio, b1, w2_packed16, b2):
 
 
 def sepconv_fused(x, w_33c, bias_dw, w_packed16, bias_pw, cout, pre_relu=False, dw_relu=False, out_relu=False):
-    """A whole separable conv (depthwise 3x3 stride 1 + pointwise, cin in {64, 128} -> 128) in one kernel."""
+    """A whole separable conv (depthwise 3x3 stride 1 + pointwise) in one kernel: cin in {64, 128} -> 128, or
+    cin % 16 == 0 -> 256."""
     b, h, w, c = x.shape
     y = torch.empty((b, h, w, cout), dtype=f32, device=x.device)
     call("asr_sepconv_fused_f16x3", ptr(x), ptr(w_33c), ptr(bias_dw), ptr(w_packed16), ptr(bias_pw), ptr(y), b, h, w, c, cout, c,

@@ -180,14 +180,15 @@ def test_entry_stem_fused_matches_the_two_kernels(dev, b, h, w_):
     np.testing.assert_allclose(got, ref, rtol=0, atol=5e-5)
 
 
-@pytest.mark.parametrize("c,b,h,w_,depth_act", [(128, 2, 24, 40, False), (64, 2, 17, 30, False), (128, 1, 8, 14, True),
-                                                 (64, 3, 33, 15, True)])
-def test_sepconv_fused_is_bit_identical_to_the_two_kernels(dev, c, b, h, w_, depth_act):
+@pytest.mark.parametrize("c,n,b,h,w_,depth_act", [(128, 128, 2, 24, 40, False), (64, 128, 2, 17, 30, False),
+                                                   (128, 128, 1, 8, 14, True), (64, 128, 3, 33, 15, True),
+                                                   (256, 256, 2, 24, 40, False), (128, 256, 1, 19, 30, False),
+                                                   (304, 256, 2, 16, 28, True), (48, 256, 1, 9, 17, True)])
+def test_sepconv_fused_is_bit_identical_to_the_two_kernels(dev, c, n, b, h, w_, depth_act):
     """depthwise -> LDS (split f16) -> MFMA GEMM in one kernel against asr_dwconv3x3_nhwc_f32 + asr_pwconv_mfma_f16x3:
     same depthwise arithmetic, same MFMA sequence per accumulator -> bitwise equal; ragged 8 x 14 tiles and image borders."""
     from asr_amd import ops
     rng = np.random.default_rng(303)
-    n = 128
     x = ops.to_device(_rand(rng, b, h, w_, c))
     wd = ops.to_device(_rand(rng, 3, 3, c, scale=0.3))
     bd = ops.to_device(_rand(rng, c, scale=0.1))
