@@ -80,23 +80,31 @@ __global__ __launch_bounds__(512) void sepconv_fused_kernel(const float* __restr
 
     const int tiles_x = (w + SF_TW - 1) / SF_TW, tiles_y = (h + SF_TH - 1) / SF_TH;
     const long long total = (long long)batch * tiles_y * tiles_x;
+    // The RPT + 2 input rows of a tile for this thread (clamped addresses, no branch).  They are requested one tile ahead:
+    // right after stage 1 has consumed the current rows, so they fly under stage 2 (MFMAs, stores) of the current tile.
+    f32x4 in[RPT + 2];
+    auto request_rows = [&](long long t) {
+        const int tx0 = (int)(t % tiles_x) * SF_TW;
+        const long long tt = t / tiles_x;
+        const int ty0 = (int)(tt % tiles_y) * SF_TH;
+        const float* xin = x + (tt / tiles_y) * h * w * ldx + ch;
+        const int ixc = min(max(tx0 - 1 + lane16, 0), w - 1);
+#pragma unroll
+        for (int r = 0; r < RPT + 2; ++r) {
+            const int iy = min(max(ty0 + ry0 - 1 + r, 0), h - 1);
+            in[r] = *reinterpret_cast<const f32x4*>(xin + ((long long)iy * w + ixc) * ldx);
+        }
+    };
+    if ((long long)blockIdx.x < total) request_rows(blockIdx.x);
     for (long long tile = blockIdx.x; tile < total; tile += gridDim.x) {
         const int x0 = (int)(tile % tiles_x) * SF_TW;
         const long long tt = tile / tiles_x;
         const int y0 = (int)(tt % tiles_y) * SF_TH;
         const long long b = tt / tiles_y;
-        const float* xin = x + b * h * w * ldx + ch;
         __syncthreads();                                      // the previous tile's stage 2 is done with the LDS image
-        // ---- stage 1: all RPT + 2 input rows of this thread requested up front (clamped addresses, no branch) ----
+        // ---- stage 1 ----
         const int ix = x0 - 1 + lane16;
         const bool col_ok = ix >= 0 && ix < w;
-        const int ixc = min(max(ix, 0), w - 1);
-        f32x4 in[RPT + 2];
-#pragma unroll
-        for (int r = 0; r < RPT + 2; ++r) {
-            const int iy = min(max(y0 + ry0 - 1 + r, 0), h - 1);
-            in[r] = *reinterpret_cast<const f32x4*>(xin + ((long long)iy * w + ixc) * ldx);
-        }
         f32x4 win[3][3];                                       // [window row][left, centre, right]
 #pragma unroll
         for (int r = 0; r < RPT + 2; ++r) {
@@ -140,6 +148,7 @@ __global__ __launch_bounds__(512) void sepconv_fused_kernel(const float* __restr
                 win[1][k] = win[2][k];
             }
         }
+        request_rows(min(tile + (long long)gridDim.x, total - 1));    // next tile's rows (the last tile re-requests its own)
         __syncthreads();
         // ---- stage 2: out[line][n] = sum_c A[line][c] * W[c][n] on split-f16 MFMA, A from the LDS image ----
         f32x16 acc2[2];
