@@ -406,31 +406,31 @@ __global__ __launch_bounds__(256) void gap_kernel(const float* __restrict__ x, f
 }
 
 // ---- bilinear resize, TF2 half-pixel centres ------------------------------------------------------
+// grid = (ceil(w_out * c / 4 / 256), h_out, batch): the output row and image come from the block index (the generic
+// flat index cost three 64-bit divisions per 16 output bytes -- the kernel was VALU-bound at 3 TB/s on the decoder's
+// 32^2 -> 128^2 x 256-channel upsample), the row's y taps are block-uniform.
 __global__ __launch_bounds__(256) void resize_bilinear_kernel(const float* __restrict__ x, float* __restrict__ y, int batch,
                                                               int h_in, int w_in, int c, int h_out, int w_out, int ldx,
                                                               int ldy, float scale_y, float scale_x) {
-    const int c4n = c >> 2;
-    const long long total = (long long)batch * h_out * w_out * c4n;
-    for (long long o = (long long)blockIdx.x * 256 + threadIdx.x; o < total; o += (long long)gridDim.x * 256) {
-        const int c4 = (int)(o % c4n);
-        long long t = o / c4n;
-        const int ox = (int)(t % w_out); t /= w_out;
-        const int oy = (int)(t % h_out);
-        const long long b = t / h_out;
-        const float py = ((float)oy + 0.5f) * scale_y - 0.5f, px = ((float)ox + 0.5f) * scale_x - 0.5f;
-        const float fy = floorf(py), fx = floorf(px);
-        const int ylo = max((int)fy, 0), yhi = min((int)ceilf(py), h_in - 1);
-        const int xlo = max((int)fx, 0), xhi = min((int)ceilf(px), w_in - 1);
-        const float ty = py - fy, tx = px - fx;
-        const float* base = x + b * h_in * w_in * ldx + c4 * 4;
-        const f32x4 tl = *reinterpret_cast<const f32x4*>(base + ((long long)ylo * w_in + xlo) * ldx);
-        const f32x4 tr = *reinterpret_cast<const f32x4*>(base + ((long long)ylo * w_in + xhi) * ldx);
-        const f32x4 bl = *reinterpret_cast<const f32x4*>(base + ((long long)yhi * w_in + xlo) * ldx);
-        const f32x4 br = *reinterpret_cast<const f32x4*>(base + ((long long)yhi * w_in + xhi) * ldx);
-        const f32x4 top = tl + (tr - tl) * tx;
-        const f32x4 bot = bl + (br - bl) * tx;
-        *reinterpret_cast<f32x4*>(y + ((b * h_out + oy) * w_out + ox) * ldy + c4 * 4) = top + (bot - top) * ty;
-    }
+    const unsigned c4n = (unsigned)c >> 2;
+    const unsigned idx = blockIdx.x * 256u + threadIdx.x;
+    const unsigned ox = idx / c4n, c4 = idx - ox * c4n;
+    if (ox >= (unsigned)w_out) return;
+    const int oy = blockIdx.y;
+    const long long b = blockIdx.z;
+    const float py = ((float)oy + 0.5f) * scale_y - 0.5f, px = ((float)ox + 0.5f) * scale_x - 0.5f;
+    const float fy = floorf(py), fx = floorf(px);
+    const int ylo = max((int)fy, 0), yhi = min((int)ceilf(py), h_in - 1);
+    const int xlo = max((int)fx, 0), xhi = min((int)ceilf(px), w_in - 1);
+    const float ty = py - fy, tx = px - fx;
+    const float* base = x + b * h_in * w_in * ldx + c4 * 4;
+    const f32x4 tl = *reinterpret_cast<const f32x4*>(base + ((long long)ylo * w_in + xlo) * ldx);
+    const f32x4 tr = *reinterpret_cast<const f32x4*>(base + ((long long)ylo * w_in + xhi) * ldx);
+    const f32x4 bl = *reinterpret_cast<const f32x4*>(base + ((long long)yhi * w_in + xlo) * ldx);
+    const f32x4 br = *reinterpret_cast<const f32x4*>(base + ((long long)yhi * w_in + xhi) * ldx);
+    const f32x4 top = tl + (tr - tl) * tx;
+    const f32x4 bot = bl + (br - bl) * tx;
+    *reinterpret_cast<f32x4*>(y + ((b * h_out + oy) * w_out + ox) * ldy + c4 * 4) = top + (bot - top) * ty;
 }
 
 int cap_grid(long long total) {
@@ -527,10 +527,10 @@ extern "C" int asr_resize_bilinear_f32(const float* x, float* y, int batch, int 
                 "asr_resize_bilinear_f32: bad shape");
     ASR_UNSUPPORTED((c & 3) || (ldx & 3) || (ldy & 3) || ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15),
                     "asr_resize_bilinear_f32: c, ldx, ldy multiples of 4 and 16-byte aligned pointers required");
-    const long long total = (long long)batch * h_out * w_out * (c >> 2);
     const float sy = (float)h_in / (float)h_out, sx = (float)w_in / (float)w_out;
-    hipLaunchKernelGGL(resize_bilinear_kernel, dim3(cap_grid(total)), dim3(256), 0, asr_stream(stream), x, y, batch, h_in,
-                       w_in, c, h_out, w_out, ldx, ldy, sy, sx);
+    ASR_UNSUPPORTED(batch > 65535 || h_out > 65535, "asr_resize_bilinear_f32: batch and h_out must not exceed 65535 (grid dimensions)");
+    hipLaunchKernelGGL(resize_bilinear_kernel, dim3((unsigned)asr_cdiv((long long)w_out * (c >> 2), 256), (unsigned)h_out, (unsigned)batch),
+                       dim3(256), 0, asr_stream(stream), x, y, batch, h_in, w_in, c, h_out, w_out, ldx, ldy, sy, sx);
     ASR_LAUNCH_CHECK();
     return ASR_OK;
 }
