@@ -79,15 +79,16 @@ template <int C>
 __global__ __launch_bounds__(kThreads) void augment_copies_kernel(
     const float* __restrict__ image, float* __restrict__ copies,
     const float* __restrict__ rot_tf, const float* __restrict__ trans_tf, int n, int h, int w) {
-    const int64_t total = (int64_t)n * h * w;
+    // grid = (ceil(w / kThreads), h, n): row and copy come from the block index -- no 64-bit divisions per pixel, and
+    // the copy's two transforms are block-uniform (scalar loads)
     PixC<C> zero;
 #pragma unroll
     for (int ch = 0; ch < C; ++ch) zero.v[ch] = 0.0f;
-    for (int64_t p = (int64_t)blockIdx.x * kThreads + threadIdx.x; p < total;
-         p += (int64_t)gridDim.x * kThreads) {
-        const int x = (int)(p % w);
-        const int y = (int)((p / w) % h);
-        const int b = (int)(p / ((int64_t)w * h));
+    const int x = blockIdx.x * kThreads + threadIdx.x;
+    const int y = blockIdx.y;
+    const int b = blockIdx.z;
+    if (x < w) {
+        const int64_t p = ((int64_t)b * h + y) * w + x;
         const AsrTf8 tr = asr_load_tf(rot_tf + (int64_t)b * 8);
         const AsrTf8 tt = asr_load_tf(trans_tf + (int64_t)b * 8);
         float ix, iy;
@@ -166,8 +167,8 @@ extern "C" int asr_augment_copies_f32(const float* image, float* copies, const f
                                       asr_stream_t stream) {
     ASR_REQUIRE(image && copies && rot_tf && trans_tf, "asr_augment_copies_f32: null pointer");
     ASR_REQUIRE(n > 0 && h > 0 && w > 0, "asr_augment_copies_f32: bad shape n=%d %dx%d", n, h, w);
-    const int64_t total = (int64_t)n * h * w;
-    const dim3 grid(grid_for(total)), block(kThreads);
+    ASR_UNSUPPORTED(n > 65535 || h > 65535, "asr_augment_copies_f32: n and h must not exceed 65535 (grid dimensions)");
+    const dim3 grid((unsigned)((w + kThreads - 1) / kThreads), (unsigned)h, (unsigned)n), block(kThreads);
     hipStream_t s = asr_stream(stream);
     switch (c) {
         case 1: hipLaunchKernelGGL(augment_copies_kernel<1>, grid, block, 0, s, image, copies, rot_tf, trans_tf, n, h, w); break;
