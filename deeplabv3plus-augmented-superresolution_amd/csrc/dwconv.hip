@@ -191,6 +191,12 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 // ACT: 0 = activations from the runtime flags, 1 = pre-ReLU only (the sepconvs without depth activation), 2 = post-ReLU
 // only (with depth activation) -- at ~5 TB/s these kernels are bound by VALU issue (3 waves per SIMD, ~150 instructions
 // per output row), and a runtime flag costs a v_max + v_cndmask per loaded element instead of one v_max.
+// Streaming (non-temporal) output stores: the depthwise output is consumed by the NEXT kernel, never by this one, and a
+// normal store leaves 300 MB marching through L2; same-box A/B over all depthwise launches: 12.75 -> 12.1-12.7 ms (-DASR_DW_NT=0 to compare).
+#ifndef ASR_DW_NT
+#define ASR_DW_NT 1
+#endif
+constexpr bool kNtStores = ASR_DW_NT != 0;
 template <int R, int S, int SROWS, int PF, bool SPLIT, int ACT>
 __global__ __launch_bounds__(256) void dw_stream_full_kernel(DwArgs p, int tiles_x) {
     constexpr int WIN = 2 * R + 1;
@@ -239,8 +245,8 @@ __global__ __launch_bounds__(256) void dw_stream_full_kernel(DwArgs p, int tiles
 
     auto issue = [&](int iy, f32x4 (&d)[3]) {                 // three unconditional loads from a clamped row
         const float* row = xin + (long long)min(max(iy, 0), p.h_in - 1) * row_stride;
-        d[0] = *reinterpret_cast<const f32x4*>(row + ofl);
-        d[1] = *reinterpret_cast<const f32x4*>(row + ofc);
+        d[0] = *reinterpret_cast<const f32x4*>(row + ofl);     // (non-temporal LOADS are 20 % slower: the two neighbour
+        d[1] = *reinterpret_cast<const f32x4*>(row + ofc);     //  columns are L1 hits of other lanes' centre loads)
         d[2] = *reinterpret_cast<const f32x4*>(row + ofr);
     };
     auto enter = [&](int iy, const f32x4 (&d)[3], f32x4 (&w)[3]) {   // top / bottom zero padding + pre-activation at window entry
@@ -307,9 +313,9 @@ __global__ __launch_bounds__(256) void dw_stream_full_kernel(DwArgs p, int tiles
                 const u32x4 out = even ? u32x4{h2.x, h2.y, got.x, got.y} : u32x4{got.x, got.y, l2.x, l2.y};
                 // even lane: hi of channels ch .. ch+7 at its own hi slot; odd lane: lo of channels ch-4 .. ch+3 at the lo slot
                 _Float16* o = ysplit + (long long)(oy0 + r) * split_row_stride + (even ? 0 : 32 - 4);
-                *reinterpret_cast<u32x4*>(o) = out;
+                if (kNtStores) __builtin_nontemporal_store(out, reinterpret_cast<u32x4*>(o)); else *reinterpret_cast<u32x4*>(o) = out;
             } else {
-                *reinterpret_cast<f32x4*>(yout + (long long)(oy0 + r) * p.w_out * p.ldy) = acc;
+                if (kNtStores) __builtin_nontemporal_store(acc, reinterpret_cast<f32x4*>(yout + (long long)(oy0 + r) * p.w_out * p.ldy)); else *reinterpret_cast<f32x4*>(yout + (long long)(oy0 + r) * p.w_out * p.ldy) = acc;
             }
         }
     }
