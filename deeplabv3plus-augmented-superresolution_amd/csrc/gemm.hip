@@ -123,6 +123,74 @@ __device__ __forceinline__ void pw_epilogue(const PwArgs& p, f32x16 (&acc)[TM][T
     }
 }
 
+// pw_epilogue for accumulators of v_mfma_f32_16x16x32_f16: acc[rt][ct] (f32x4) holds rows rt * 16 + 4 * (lane >> 4) + r
+// (r = 0..3), column ct * 16 + (lane & 15) of the wave's (RT * 16) x (CT * 16) sub-tile.  Same LDS transposition, residual
+// prefetch and 16-byte stores as pw_epilogue<..., RES_AHEAD = true>; only the staging map differs.
+template <int WM, int WN, int RT, int CT>
+__device__ __forceinline__ void pw_epilogue16(const PwArgs& p, f32x4 (&acc)[RT][CT], float* smem, int tile_m, int tile_n, int wave, int lane) {
+    constexpr int BM = WM * RT * 16, BN = WN * CT * 16, WCOLS = CT * 16;
+    constexpr int LPR = WCOLS / 4, RPI = 64 / LPR;
+    const int wm = wave / WN, wn = wave % WN;
+    const int l16 = lane & 15, q4 = lane >> 4;
+    float* const stage = smem + wave * (32 * WCOLS);
+    const bool vec_ok = ((p.N & 3) == 0) && ((p.ldy & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.y) & 15) == 0) &&
+                        (!p.res || (((p.ldres & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.res) & 15) == 0)));
+    const int n_wave = tile_n * BN + wn * WCOLS;
+    const int c4 = lane % LPR, r_in = lane / LPR;
+    const int n = n_wave + c4 * 4;
+    const bool res_vec = vec_ok && p.res != nullptr;
+    float bv[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+        const int nj = n_wave + ct * 16 + l16;
+        bv[ct] = (p.bias && nj < p.N) ? p.bias[nj] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < RT / 2; ++i) {                         // 32-row slabs
+        const long long m_base = (long long)tile_m * BM + (wm * RT + 2 * i) * 16;
+        f32x4 rv[32 / RPI];
+        if (res_vec) {
+            const float* rbase = p.res + (n < p.N ? n : 0);
+#pragma unroll
+            for (int q = 0; q < 32 / RPI; ++q) {
+                const long long m = m_base + q * RPI + r_in;
+                rv[q] = *reinterpret_cast<const f32x4*>(rbase + (m < p.M ? m : p.M - 1) * p.ldres);
+            }
+        }
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = acc[2 * i + h2][ct][r] + bv[ct];
+                    if (p.relu) v = fmaxf(v, 0.f);
+                    if (p.relu == 2) v = fminf(v, 6.f);
+                    stage[(h2 * 16 + 4 * q4 + r) * WCOLS + ct * 16 + l16] = v;
+                }
+#pragma unroll
+        for (int q = 0; q < 32 / RPI; ++q) {
+            const int r = q * RPI + r_in;
+            const long long m = m_base + r;
+            f32x4 v = *reinterpret_cast<const f32x4*>(stage + r * WCOLS + c4 * 4);
+            if (m < p.M && n < p.N) {
+                if (vec_ok) {
+                    if (p.res) v += rv[q];
+                    *reinterpret_cast<f32x4*>(p.y + m * p.ldy + n) = v;
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+                        if (n + t < p.N) {
+                            float o = v[t];
+                            if (p.res) o += p.res[m * p.ldres + n + t];
+                            p.y[m * p.ldy + n + t] = o;
+                        }
+                }
+            }
+        }
+    }
+}
+
 template <int WM, int WN, int TM, int TN, bool CONV, bool DBUF>
 __global__ __launch_bounds__(256) void pw_gemm_kernel(PwArgs p) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
@@ -545,7 +613,7 @@ __device__ __forceinline__ void glds16(const void* g, void* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((asr_gbl_ptr)g, (asr_lds_ptr)lds_wave_base, 16, 0, 0);
 }
 
-template <int WM, int WN, int TM, int TN>
+template <int WM, int WN, int TM, int TN, bool M16>
 __global__ __launch_bounds__(WM * WN * 64, 2) void pw_gemm_f16x3_pre_kernel(PwArgs p) {
     constexpr int NT = WM * WN * 64, BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int A_BYTES = BM * 128, B_BYTES = 4 * BN * 16, STAGE_BYTES = A_BYTES + 2 * B_BYTES;
@@ -591,13 +659,27 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void pw_gemm_f16x3_pre_kernel(PwAr
         }
     };
 
-    f32x16 acc[TM][TN];
+    // M16: v_mfma_f32_16x16x32_f16 (one MFMA spans the whole 32-deep K-step) instead of v_mfma_f32_32x32x16_f16.  Same
+    // flops per cycle on paper, but under the chip's power management the 16x16x32 shape sustains ~1.18x the rate of the
+    // 32x32x16 one (tools/ubench_mfma_shapes.hip: 1.55-1.82 vs 1.86-2.20 PFLOP/s in bare loops), and this K loop runs AT
+    // the sustained MFMA rate (the clock gives back whatever a reordering of requests and MFMAs gains).
+    f32x16 acc[M16 ? 1 : TM][M16 ? 1 : TN];
+    f32x4 acc16[M16 ? 2 * TM : 1][M16 ? 2 * TN : 1];
+    if (M16) {
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < 2 * TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+            for (int j = 0; j < 2 * TN; ++j)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+                for (int e = 0; e < 4; ++e) acc16[M16 ? i : 0][M16 ? j : 0][e] = 0.f;
+    } else {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[M16 ? 0 : i][M16 ? 0 : j][e] = 0.f;
+    }
 
     const int KT = p.Kpad / BK;
 #ifdef ASR_GEMM_PHASE_PROFILE
@@ -613,6 +695,29 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void pw_gemm_f16x3_pre_kernel(PwAr
         // half of the waves request theirs after their MFMAs, measured equal / 8 % slower).
         if (kt + 1 < KT) issue_tile(kt + 1, (kt + 1) & 1);     // the other stage: last read before the previous barrier
         PHASE_MARK(1);
+        if (M16) {
+            const int l16 = lane & 15, oct = lane >> 4;        // A: row = l16, k = 8 oct ..; B: column = l16, same k
+            f16x8 ah[2 * TM], al[2 * TM];
+#pragma unroll
+            for (int i = 0; i < 2 * TM; ++i) {
+                const int row = (wm * 2 * TM + i) * 16 + l16, swz = (row >> 1) & 7;
+                ah[i] = *reinterpret_cast<const f16x8*>(st + row * 128 + ((oct ^ swz) << 4));
+                al[i] = *reinterpret_cast<const f16x8*>(st + row * 128 + (((4 + oct) ^ swz) << 4));
+            }
+#pragma unroll
+            for (int j = 0; j < 2 * TN; ++j) {
+                const int col = (wn * 2 * TN + j) * 16 + l16;
+                const f16x8 bh = *reinterpret_cast<const f16x8*>(st + A_BYTES + (oct * BN + col) * 16);
+                const f16x8 bl = *reinterpret_cast<const f16x8*>(st + A_BYTES + B_BYTES + (oct * BN + col) * 16);
+#pragma unroll
+                for (int i = 0; i < 2 * TM; ++i) {
+                    f32x4& a4 = acc16[M16 ? i : 0][M16 ? j : 0];
+                    a4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh, a4, 0, 0, 0);
+                    a4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl, a4, 0, 0, 0);
+                    a4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bh, a4, 0, 0, 0);
+                }
+            }
+        } else
         if (!(p.debug & 8))
 #pragma unroll
         for (int s = 0; s < BK / 16; ++s) {
@@ -643,8 +748,12 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void pw_gemm_f16x3_pre_kernel(PwAr
         __syncthreads();                                       // next stage landed (vmcnt(0)) and everyone is done reading this one
         PHASE_MARK(6);
     }
-    if (!(p.debug & 1)) pw_epilogue<WM, WN, TM, TN, true>(p, acc, smem, tile_m, tile_n, wave, lane);
-    else if (acc[0][0][0] == 12345.678f) p.y[0] = acc[1][3][5] + acc[0][1][2];
+    if (M16) {
+        if (!(p.debug & 1)) pw_epilogue16<WM, WN, (M16 ? 2 * TM : 2), (M16 ? 2 * TN : 1)>(p, reinterpret_cast<f32x4(&)[M16 ? 2 * TM : 2][M16 ? 2 * TN : 1]>(acc16), smem, tile_m, tile_n, wave, lane);
+    } else {
+        if (!(p.debug & 1)) pw_epilogue<WM, WN, (M16 ? 1 : TM), (M16 ? 1 : TN), true>(p, acc, smem, tile_m, tile_n, wave, lane);
+        else if (acc[0][0][0] == 12345.678f) p.y[0] = acc[0][0][5];
+    }
 #ifdef ASR_GEMM_PHASE_PROFILE
     PHASE_WAIT_VM();
     PHASE_MARK(7);
@@ -918,7 +1027,9 @@ extern "C" int asr_pwconv_mfma_f16x3_presplit(const void* x_split, const float* 
     constexpr size_t lds = 2 * (bm * 128 + 2 * 4 * bn * 16);
     // (a persistent one-workgroup-per-CU form that requests the next output tile's first K tile before the epilogue of the
     // current one, staging the epilogue through a single LDS stage, measured equal: -2 % .. +4 %; not kept)
-    auto kern = pw_gemm_f16x3_pre_kernel<4, 2, 2, 4>;
+    // ASR_PRE_MFMA=32: the v_mfma_f32_32x32x16_f16 form (bit-identical to the in-kernel-split kernel) instead of 16x16x32
+    static const bool m32 = getenv("ASR_PRE_MFMA") && atoi(getenv("ASR_PRE_MFMA")) == 32;
+    auto kern = m32 ? pw_gemm_f16x3_pre_kernel<4, 2, 2, 4, false> : pw_gemm_f16x3_pre_kernel<4, 2, 2, 4, true>;
     static bool attr_set = false;
     if (!attr_set) {
         ASR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

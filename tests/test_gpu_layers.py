@@ -2,6 +2,8 @@
 float64 references of the same op.  Tolerances: f32 MFMA == k-ordered fmaf chain, so GEMM-like
 outputs are compared with rtol 1e-4 / atol 1e-4 against a float64 reference (K <= 2048, O(1)
 operands); memory-bound layers with atol 1e-5."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -287,27 +289,40 @@ def test_gap_and_resize(dev):
 
 
 @pytest.mark.parametrize("c,n,hw,stride,rate", [(728, 728, 32, 1, 1), (256, 256, 32, 2, 1), (96, 256, 16, 1, 2), (1536, 2048, 16, 1, 2)])
-def test_presplit_sepconv_is_bit_identical_to_the_f32_handoff(dev, c, n, hw, stride, rate):
-    """dw -> split-f16 chunks -> LDS-DMA GEMM (256 x 256 tile) against dw -> f32 -> split-f16 GEMM: the same hi / lo
-    halves enter the same MFMA sequence, so the outputs must be bitwise equal (tails: M, K and N not multiples of the tile)."""
+def test_presplit_sepconv_matches_the_f32_handoff(dev, c, n, hw, stride, rate):
+    """dw -> split-f16 chunks -> LDS-DMA GEMM (256 x 256 tile) against dw -> f32 -> split-f16 GEMM: the same hi / lo halves
+    enter the same three products.  With ASR_PRE_MFMA=32 (v_mfma_f32_32x32x16_f16, the in-kernel-split kernel's shape and
+    k order) the outputs are bitwise equal; the default v_mfma_f32_16x16x32_f16 form sums each 32-deep K-step in one MFMA,
+    so it differs by f32 summation-order noise only: both must sit within 4e-6 * sum |x||w| of the float64 product
+    (the bound of test_pwconv_split_f16_is_f32_grade).  Tails: M, K and N not multiples of the tile."""
     from asr_amd import ops
     rng = np.random.default_rng(61)
     b = 3
     x = ops.to_device(_rand(rng, b, hw, hw, c))
     wd = ops.to_device(_rand(rng, 3, 3, c, scale=0.3))
     bd = ops.to_device(_rand(rng, c, scale=0.1))
-    wk = ops.to_device(_rand(rng, c, n, scale=(1.0 / c) ** 0.5))
-    bk = ops.to_device(_rand(rng, n, scale=0.1))
+    wk_h = _rand(rng, c, n, scale=(1.0 / c) ** 0.5)
+    wk = ops.to_device(wk_h)
+    bk_h = _rand(rng, n, scale=0.1)
+    bk = ops.to_device(bk_h)
     w16 = ops.pack_pw_weights_f16x3(wk)
     out_hw = (hw, hw) if stride == 1 else ((hw + 2 * rate - (2 * rate + 1)) // stride + 1,) * 2
     ref_dw = ops.dwconv3x3(x, wd, bd, stride=stride, rate=rate, out_hw=out_hw, pre_relu=True, post_relu=False)
     m = ref_dw.shape[0] * ref_dw.shape[1] * ref_dw.shape[2]
-    res = ops.to_device(_rand(rng, m, n))
+    res_h = _rand(rng, m, n)
+    res = ops.to_device(res_h)
     ref = ops.pwconv(ref_dw.reshape(m, c), w16, bk, c, n, residual=res, relu=True, f16x3=True)
     xs, (bb, ho, wo), chunks = ops.dwconv3x3_split(x, wd, bd, stride=stride, rate=rate, pre_relu=True, post_relu=0)
     assert bb * ho * wo == m and chunks == (c + 31) // 32
     got = ops.pwconv_presplit(xs, w16, bk, c, n, chunks, residual=res, relu=1)
-    assert torch.equal(got, ref)
+    if os.environ.get("ASR_PRE_MFMA") == "32":
+        assert torch.equal(got, ref)
+    a64 = ref_dw.reshape(m, c).cpu().numpy().astype(np.float64)
+    exact = np.maximum(a64 @ wk_h.astype(np.float64) + bk_h, 0) + res_h
+    bound = np.abs(a64) @ np.abs(wk_h).astype(np.float64) + np.abs(bk_h) + np.abs(res_h)
+    for out in (got, ref):
+        assert (np.abs(out.cpu().numpy() - exact) / bound).max() <= 4e-6
+    assert float((got - ref).abs().max()) <= 4e-6 * float(bound.max())
     # the split buffer itself: hi + lo reproduces the f32 depthwise output to 2^-22, padding channels are zero
     halves = xs.view(torch.float16).reshape(m, chunks, 2, 32).float()
     rec = (halves[:, :, 0, :] + halves[:, :, 1, :]).reshape(m, chunks * 32)
