@@ -762,6 +762,105 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void pw_gemm_f16x3_pre_kernel(PwAr
 #endif
 }
 
+// =================================================================================================
+// Three-stage form of the pre-split kernel: 256 x 128 tile (8 waves of 64 x 64, 16 v_mfma_f32_16x16x32_f16 tiles each),
+// three 48 KB LDS stages, the DMA requests run TWO K-steps ahead, and the two waves that share a SIMD take opposite
+// orders: waves 0-3 request their 6 pieces of K-step kt + 2 BEFORE their 48 MFMAs of K-step kt, waves 4-7 AFTER theirs.
+// tools/ubench_glds_mfma.hip shows what this buys: a wave's MFMAs run at the pipe's rate (32.0 cycles per 32 Kflop)
+// whether or not the SIMD's other wave is issuing LDS-DMA pieces, while the issuing wave pays ~160 cycles per piece --
+// so one wave of a SIMD can sit in the vector-memory queue for free as long as its partner owns the matrix pipe.  The
+// two-stage kernel cannot do this (a late request would have to land within the same K-step); the third stage is what
+// the smaller tile buys.  Waits are counted (vmcnt(6): only the pieces requested in the current K-step may be in flight).
+// =================================================================================================
+template <int N> __device__ __forceinline__ void asr_wait_vmcnt() {
+    __builtin_amdgcn_s_waitcnt((N & 15) | ((N >> 4) << 14) | (7 << 4) | (15 << 8));
+}
+
+__global__ __launch_bounds__(512, 2) void pw_gemm_f16x3_pre3_kernel(PwArgs p) {
+    constexpr int NT = 512, BM = 256, BN = 128, RT = 4, CT = 4, WN = 2;
+    constexpr int A_BYTES = BM * 128, B_BYTES = 4 * BN * 16, STAGE_BYTES = A_BYTES + 2 * B_BYTES;     // 32 + 8 + 8 KB
+    constexpr int PA = BM * 8 / NT;                            // 4 A pieces per thread; B: one per thread and plane
+    constexpr int PIECES = PA + 2;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    char* const lds = reinterpret_cast<char*>(smem);
+
+    const int nwg = gridDim.x, orig = blockIdx.x;
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
+    const int lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+    const int tile_m = lid / p.tiles_n, tile_n = lid % p.tiles_n;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int l16 = lane & 15, oct = lane >> 4;
+    const bool early = wave < 4;                               // waves w and w + 4 share SIMD w % 4
+
+    const char* a_src[PA];
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+        const int q = tid + NT * i, row = q >> 3, slot = (q & 7) ^ ((row >> 1) & 7);
+        long long m = (long long)tile_m * BM + row;
+        if (m >= p.M) m = p.M - 1;
+        a_src[i] = reinterpret_cast<const char*>(p.x) + (m * p.ldx) * 128 + slot * 16;           // + kt * 128 per K chunk
+    }
+    const long long plane_bytes = (long long)p.Kpad * p.Npad * 2;
+    const char* const b_src = reinterpret_cast<const char*>(p.wp) + (((long long)(tid >> 7) * p.Npad) + (long long)tile_n * BN + (tid & 127)) * 16;
+    const long long b_kstep = (long long)4 * p.Npad * 16;
+
+    auto issue = [&](int kt) {
+        char* const st = lds + (kt % 3) * STAGE_BYTES;
+#pragma unroll
+        for (int i = 0; i < PA; ++i) glds16(a_src[i] + (long long)kt * 128, st + (wave * 64 + NT * i) * 16);
+        glds16(b_src + kt * b_kstep, st + A_BYTES + wave * 64 * 16);
+        glds16(b_src + kt * b_kstep + plane_bytes, st + A_BYTES + B_BYTES + wave * 64 * 16);
+    };
+
+    f32x4 acc[RT][CT];
+#pragma unroll
+    for (int i = 0; i < RT; ++i)
+#pragma unroll
+        for (int j = 0; j < CT; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
+
+    const int KT = p.Kpad / BK;
+    issue(0);
+    if (KT > 1) issue(1);
+    if (KT > 1) asr_wait_vmcnt<PIECES>(); else asr_wait_vmcnt<0>();      // K-step 0 landed; K-step 1 may still be in flight
+    __builtin_amdgcn_s_barrier();
+    for (int kt = 0; kt < KT; ++kt) {
+        const char* const st = lds + (kt % 3) * STAGE_BYTES;
+        const bool more2 = kt + 2 < KT;
+        if (early && more2) issue(kt + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        f16x8 ah[RT], al[RT];
+#pragma unroll
+        for (int i = 0; i < RT; ++i) {
+            const int row = (wm * RT + i) * 16 + l16, swz = (row >> 1) & 7;
+            ah[i] = *reinterpret_cast<const f16x8*>(st + row * 128 + ((oct ^ swz) << 4));
+            al[i] = *reinterpret_cast<const f16x8*>(st + row * 128 + (((4 + oct) ^ swz) << 4));
+        }
+#pragma unroll
+        for (int j = 0; j < CT; ++j) {
+            const int col = (wn * CT + j) * 16 + l16;
+            const f16x8 bh = *reinterpret_cast<const f16x8*>(st + A_BYTES + (oct * BN + col) * 16);
+            const f16x8 bl = *reinterpret_cast<const f16x8*>(st + A_BYTES + B_BYTES + (oct * BN + col) * 16);
+#pragma unroll
+            for (int i = 0; i < RT; ++i) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh, acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl, acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bh, acc[i][j], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (!early && more2) issue(kt + 2);
+        // K-step kt + 1 must have landed before anyone reads it: everything but the pieces requested in THIS K-step
+        if (more2) asr_wait_vmcnt<PIECES>();
+        else asr_wait_vmcnt<0>();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // this wave's LDS reads of the stage are done
+        __builtin_amdgcn_s_barrier();
+    }
+    if (!(p.debug & 1)) pw_epilogue16<4, WN, RT, CT>(p, acc, smem, tile_m, tile_n, wave, lane);
+}
+
 // w [K][N] f32 -> two half planes [Kpad/8][Npad][8] (hi then lo), zero padded
 __global__ __launch_bounds__(256) void pack_weights_f16x3_kernel(const float* __restrict__ w, _Float16* __restrict__ wp, int K,
                                                                  int N, int Kpad, int Npad) {
@@ -1016,6 +1115,25 @@ extern "C" int asr_pwconv_mfma_f16x3_presplit(const void* x_split, const float* 
     a.ldx = ldx_chunks; a.ldy = ldy; a.ldres = ldres; a.relu = relu;
     a.taps = 1; a.cin = k; a.stride = 1; a.pad = 0; a.dil = 1;
     ASR_REQUIRE(ldx_chunks * BK >= a.Kpad, "asr_pwconv_mfma_f16x3_presplit: ldx_chunks * 32 < ceil32(k)");
+    // ASR_PRE_KERNEL=3: the three-stage 256 x 128 kernel (any n); default: the two-stage 256 x 256 kernel
+    static const bool three = getenv("ASR_PRE_KERNEL") && atoi(getenv("ASR_PRE_KERNEL")) == 3;
+    if (three) {
+        ASR_UNSUPPORTED(reinterpret_cast<uintptr_t>(x_split) & 127, "asr_pwconv_mfma_f16x3_presplit: x_split must be 128-byte aligned");
+        static const int dbg3 = getenv("ASR_GEMM_DEBUG") ? atoi(getenv("ASR_GEMM_DEBUG")) : 0;
+        a.debug = dbg3;
+        a.tiles_n = (int)asr_cdiv(n, 128);
+        const long long nwg3 = asr_cdiv(m, 256) * a.tiles_n;
+        ASR_REQUIRE(nwg3 <= 0x7fffffffLL, "asr_pwconv_mfma_f16x3_presplit: grid too large");
+        constexpr size_t lds3 = 3 * (256 * 128 + 2 * 4 * 128 * 16);
+        static bool attr3 = false;
+        if (!attr3) {
+            ASR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pw_gemm_f16x3_pre3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
+            attr3 = true;
+        }
+        hipLaunchKernelGGL(pw_gemm_f16x3_pre3_kernel, dim3((unsigned)nwg3), dim3(512), lds3, asr_stream(stream), a);
+        ASR_LAUNCH_CHECK();
+        return ASR_OK;
+    }
     ASR_UNSUPPORTED(a.Npad % 256 != 0, "asr_pwconv_mfma_f16x3_presplit: ceil128(n) must be a multiple of 256 (n=%d)", n);
     ASR_UNSUPPORTED(reinterpret_cast<uintptr_t>(x_split) & 127, "asr_pwconv_mfma_f16x3_presplit: x_split must be 128-byte aligned");
     constexpr int bm = 256, bn = 256;
