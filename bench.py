@@ -56,16 +56,48 @@ def synth_image(rng, size=IMG, box=8):
     return np.ascontiguousarray(s, dtype=np.float32)
 
 
-def synth_gt(rng, size=IMG):
-    """class-8 blob with a void (255) border, other pixels background."""
-    yy, xx = np.mgrid[0:size, 0:size].astype(np.float32)
-    cy, cx = size * (0.4 + 0.2 * rng.random()), size * (0.4 + 0.2 * rng.random())
-    ry, rx = size * (0.15 + 0.15 * rng.random()), size * (0.15 + 0.15 * rng.random())
-    d = ((yy - cy) / ry) ** 2 + ((xx - cx) / rx) ** 2
-    gt = np.zeros((size, size), np.int32)
-    gt[d < 1.15] = 255
-    gt[d < 1.0] = CLASS_ID
-    return gt
+def calibrate_class_bias(model, image_dev, class_id, fraction=0.3):
+    """Seeded synthetic weights never make class `class_id` the argmax on low-passed noise, which would hand the SR stage
+    an empty problem.  Shift that class's logit bias (a synthetic parameter like all the others) so that it wins on
+    `fraction` of the pixels of the un-augmented global image 0; every rank computes the same shift from the same image."""
+    import torch
+    logits = model.predict_device(image_dev[None], batch_size=1)[0]
+    other = logits.clone()
+    other[..., class_id] = float("-inf")
+    margin = (other.max(dim=-1).values - logits[..., class_id]).flatten()
+    delta = float(torch.quantile(margin, fraction))
+    model.engine.shift_logit_bias(class_id, delta)
+    return delta
+
+
+def model_gt(path, model, image_dev, class_id, ring=4):
+    """Ground truth consistent with the (synthetic) model: the standard-output mask of the un-augmented image
+    (generate_standard_output.py:52-65), eroded by `ring` pixels, with a void (255) band of 2*ring pixels around it --
+    the shape of a VOC label map (class blob, 255 border).  Setup only (torch slicing, outside the timed region)."""
+    import torch
+    std = path.standard_mask(model.predict_device(image_dev[None], batch_size=1)[0], path.sr.output_size)
+    m = (std == class_id)
+
+    def spread(mask):                 # (2*ring+1)^2 box dilation, separable
+        out = mask.clone()
+        for axis in (0, 1):
+            acc = out.clone()
+            for d in range(1, ring + 1):
+                fwd = torch.zeros_like(out)
+                bwd = torch.zeros_like(out)
+                if axis == 0:
+                    fwd[d:], bwd[:-d] = out[:-d], out[d:]
+                else:
+                    fwd[:, d:], bwd[:, :-d] = out[:, :-d], out[:, d:]
+                acc |= fwd | bwd
+            out = acc
+        return out
+
+    dil, ero = spread(m), ~spread(~m)
+    gt = torch.zeros_like(std, dtype=torch.int32)
+    gt[dil] = 255
+    gt[ero] = class_id
+    return gt.contiguous()
 
 
 def cpu_baseline(weights, seed=1234):
@@ -109,6 +141,46 @@ def cpu_baseline(weights, seed=1234):
     }
 
 
+def build_library_once():
+    """Compile libasr_hip.so if it is missing -- under an exclusive file lock, so the ranks of one launch never run
+    hipcc over the same objects at once (csrc/build.py takes the lock; the losers find the library up to date)."""
+    from asr_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__ as entry
+        entry.build()
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start N fresh ranks (one per GPU) with torch.distributed.run and
+    relay their output.  This parent never touches the GPU (torch.cuda.device_count() does not initialise HIP on this
+    image), it only builds the library, waits and returns the children's exit code.  With fewer visible devices than
+    ranks the run is a REHEARSAL of the multi-rank path (gloo collectives, ranks share devices) and says so in its
+    line; it is refused beyond 4 ranks (device memory and the per-card process limit of the GPU boxes)."""
+    import socket
+    import subprocess
+    import torch
+    build_library_once()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    ndev = torch.cuda.device_count()
+    if ndev < args.gpus:
+        if ndev == 0:
+            print(f"bench.py: --gpus {args.gpus} but no GPU is visible", file=sys.stderr)
+            return 2
+        if args.gpus > 4:
+            print(f"bench.py: --gpus {args.gpus} but only {ndev} device(s) visible; a rehearsal on shared devices is limited "
+                  f"to 4 ranks", file=sys.stderr)
+            return 2
+        env["ASR_DIST_BACKEND"] = "gloo"
+        print(f"bench.py: {ndev} device(s) for {args.gpus} ranks -> rehearsal (gloo, shared devices)", file=sys.stderr)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -124,13 +196,20 @@ def main():
                     "the other and vice versa; results are bit-identical)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-f32-line", action="store_true", help="skip the extra exact-f32 (v_mfma_f32_32x32x2_f32) measurement")
+    ap.add_argument("--dump-table", default=None, help="rank 0 writes the gathered [images, 6] IoU table (float64 .npy) here")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    if world_env != args.gpus:
+        sys.exit(f"bench.py: WORLD_SIZE={world_env} but --gpus {args.gpus}: launch one rank per GPU "
+                 f"(python bench.py --gpus N starts them itself) -- refusing to report a line for the wrong rank count")
+
     import torch
-    import __graft_entry__ as entry
     from asr_amd import _lib
-    if not os.path.exists(_lib.LIB_PATH):
-        entry.build()
+    build_library_once()
     from asr_amd import distributed as D, weights as W, ops
     from asr_amd.model import DeeplabModel
     from asr_amd.pipeline import HotPath
@@ -138,36 +217,44 @@ def main():
     from asr_amd.superresolution_scripts.superresolution import Superresolution
 
     rank, world, local_rank = D.init_from_env()
-    assert world == args.gpus or world == 1, f"WORLD_SIZE={world} but --gpus {args.gpus}"
     dev = D.local_device(local_rank)
     torch.cuda.set_device(dev)
+    rehearsal = world > 1 and torch.distributed.get_backend() != "nccl"
+    if rehearsal:           # ranks share devices: keep (ranks per device) x lanes x 30 GB of activation pools inside the HBM
+        per_dev = -(-world // max(torch.cuda.device_count(), 1))
+        args.lanes = max(1, min(args.lanes, 4 // per_dev))
 
     K, Wm = args.steps, args.warmup
     per_rank = K + Wm
     total_images = per_rank * world
     weights = W.make_synthetic_weights(1234, 21)
-    model = DeeplabModel(weights, (IMG, IMG, 3), 21, final_upsample=False, last_activation=None,
-                         precision=args.precision)
-    opt = Optimizer("adam", 1e-3, amsgrad=True, lr_scheduler=True, decay_steps=60, decay_rate=0.3)
-    sr = Superresolution(1.0, 0.3, 0.7, 0.0, num_iter=SR_ITERS, num_aug=NUM_AUG, optimizer=opt,
-                         feature_size=(FEAT, FEAT), output_size=(IMG, IMG))
-    path = HotPath(model, sr, class_id=CLASS_ID, mode="argmax", th_factor=TH_FACTOR, batch_size=args.batch_size)
+
+    def make_path(precision):
+        mdl = DeeplabModel(weights, (IMG, IMG, 3), 21, final_upsample=False, last_activation=None, precision=precision)
+        opt = Optimizer("adam", 1e-3, amsgrad=True, lr_scheduler=True, decay_steps=60, decay_rate=0.3)
+        sr = Superresolution(1.0, 0.3, 0.7, 0.0, num_iter=SR_ITERS, num_aug=NUM_AUG, optimizer=opt,
+                             feature_size=(FEAT, FEAT), output_size=(IMG, IMG))
+        return mdl, HotPath(mdl, sr, class_id=CLASS_ID, mode="argmax", th_factor=TH_FACTOR, batch_size=args.batch_size)
+
+    model, path = make_path(args.precision)
+    cur = {"path": path}                              # the path the step closures drive (swapped for the exact-f32 line)
 
     # Synthetic inputs, resident in HBM before the timed region.  Global image g = step * world + rank;
     # every rank replays the reference's sequential RNG stream and keeps its own draws.
     params = D.replay_augmentation_stream(total_images, NUM_AUG, ANGLE_MAX, SHIFT_MAX, seed=1234)
     my_globals = [s * world + rank for s in range(per_rank)]
-    distinct = min(per_rank, 8)                      # 8 distinct images per rank, cycled (content does not change the work)
-    imgs, gts = [], []
-    for j in range(distinct):
-        rng = np.random.default_rng(1234 + 1000 * rank + j)
-        imgs.append(ops.to_device(synth_image(rng), device=dev))
-        gts.append(ops.to_device(synth_gt(rng), torch.int32, device=dev))
+    distinct = 8                                     # 8 distinct images, cycled by GLOBAL index (content does not change the
+    imgs, gts = {}, {}                               # work; the same global image is the same data on any rank count)
+    bias_shift = calibrate_class_bias(model, ops.to_device(synth_image(np.random.default_rng(1234)), device=dev), CLASS_ID)
+    for j in sorted({g % distinct for g in my_globals}):
+        rng = np.random.default_rng(1234 + j)
+        imgs[j] = ops.to_device(synth_image(rng), device=dev)
+        gts[j] = model_gt(path, model, imgs[j], CLASS_ID)
 
     def step(i, profile=None):
         g = my_globals[i]
         angles, shifts = params[g]
-        return path.run_image(imgs[i % distinct], angles, shifts, gt_dev=gts[i % distinct],
+        return cur["path"].run_image(imgs[my_globals[i] % distinct], angles, shifts, gt_dev=gts[my_globals[i] % distinct],
                               adam_start=D.adam_start_step(g, SR_ITERS), profile=profile)
 
     def submit(i):
@@ -175,13 +262,13 @@ def main():
         next image's forward pass); the per-image result is collected one step later."""
         g = my_globals[i]
         angles, shifts = params[g]
-        return path.submit_image(imgs[i % distinct], angles, shifts, gt_dev=gts[i % distinct],
+        return cur["path"].submit_image(imgs[my_globals[i] % distinct], angles, shifts, gt_dev=gts[my_globals[i] % distinct],
                                  adam_start=D.adam_start_step(g, SR_ITERS))
 
     def submit_lane(i):
         g = my_globals[i]
         angles, shifts = params[g]
-        return path.submit_lane(i % args.lanes, imgs[i % distinct], angles, shifts, gt_dev=gts[i % distinct],
+        return cur["path"].submit_lane(i % args.lanes, imgs[my_globals[i] % distinct], angles, shifts, gt_dev=gts[my_globals[i] % distinct],
                                 adam_start=D.adam_start_step(g, SR_ITERS))
 
     def run_steps(first, count):
@@ -213,18 +300,21 @@ def main():
         if world > 1:
             torch.distributed.barrier()
 
-    for lane in range(args.lanes if not args.overlap else 1):       # every lane's launch plan and activation pool exist
-        fb = min(args.batch_size, NUM_AUG)                          # before the timed region, whatever the warm-up count
-        model.engine.plan(fb, IMG, IMG, lane)
-        if NUM_AUG % fb:
-            model.engine.plan(NUM_AUG % fb, IMG, IMG, lane)
-    run_steps(0, Wm)
+    def make_plans(mdl):
+        for lane in range(args.lanes if not args.overlap else 1):   # every lane's launch plan and activation pool exist
+            fb = min(args.batch_size, NUM_AUG)                      # before the timed region, whatever the warm-up count
+            mdl.engine.plan(fb, IMG, IMG, lane)
+            if NUM_AUG % fb:
+                mdl.engine.plan(NUM_AUG % fb, IMG, IMG, lane)
+
+    make_plans(model)
+    warm_records = run_steps(0, Wm)
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     records = run_steps(Wm, K)
-    table = D.all_gather_iou(my_globals[Wm:], records, total_images, device=dev)
+    table = D.all_gather_iou(my_globals, warm_records + records, total_images, device=dev)
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
@@ -249,7 +339,9 @@ def main():
         "config": {
             "workload": ("BASELINE configs[1]: synthetic 512x512 images, num_aug=100, angle+-0.15 shift+-80, argmax OPM "
                          "class 8, ASR 50 AMSGrad iters + max-SR + mean-SR + threshold + 6 IoUs; step = 1 image = 100 copies; "
-                         "DeepLabV3+ Xception-65 OS16, f32 activations/accumulation, seeded synthetic weights"),
+                         "DeepLabV3+ Xception-65 OS16, f32 activations/accumulation, seeded synthetic weights (class-8 logit bias "
+                         f"shifted by {bias_shift:+.4f} so that class 8 wins 30 % of image 0); ground truth = the model's own "
+                         "standard-output mask eroded by 4 px inside an 8 px void band"),
             "precision": args.precision,
             "images_per_gpu": K, "num_aug": NUM_AUG, "sr_iters": SR_ITERS, "forward_batch": args.batch_size,
             "parallelism": f"images sharded over {world} GPU(s), one all-gather of IoU records",
@@ -257,7 +349,12 @@ def main():
                         (f"{args.lanes} images in flight on alternating HIP streams" if args.lanes > 1 else "none")),
         },
     }
+    if rehearsal:
+        out["rehearsal"] = (f"{world} ranks on {torch.cuda.device_count()} device(s), gloo collectives: exercises sharding and the "
+                            "all-gather, NOT a scaling measurement")
     if rank == 0:
+        if args.dump_table:
+            np.save(args.dump_table, table)
         valid = table[~np.isnan(table[:, 2])]
         out["mean_ious"] = {k: (None if np.isnan(v) else round(v, 6))
                             for k, v in D.mean_ious(valid if len(valid) else table).items()}
@@ -268,8 +365,10 @@ def main():
         step(Wm, profile=prof)
         torch.cuda.synchronize()
         pmc = {}
-        pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        if os.path.exists(pmc_path):       # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/pmc_traffic.sh), gfx950-corrected
+        import glob
+        pmc_files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+        pmc_path = pmc_files[-1] if pmc_files else ""          # the newest round's PMC summary
+        if pmc_path:       # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/pmc_traffic.sh), gfx950-corrected
             with open(pmc_path) as fh:
                 pmc = json.load(fh)
 
@@ -287,8 +386,8 @@ def main():
                 "kernel": kernel, "bound": "mfma", "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(achieved / peak, 4), "peak_note": peak_note,
                 "traffic": pmc_lookup(pmc_key),
-                "traffic_note": "HBM bytes per launch from profiles/r01_pmc_traffic.json (separate FETCH_SIZE / WRITE_SIZE "
-                                "passes, FETCH doubled per the gfx950 rule)",
+                "traffic_note": f"HBM bytes per launch from profiles/{os.path.basename(pmc_path)} (separate FETCH_SIZE / "
+                                "WRITE_SIZE passes, FETCH doubled per the gfx950 rule)",
                 "algorithmic_bytes_per_launch": round(nbytes / launches),
                 "launches": launches, "avg_launch_ms": round(ms / launches, 4),
                 "algorithmic_gflop_per_launch": round(flops / launches / 1e9, 3),
@@ -298,7 +397,7 @@ def main():
 
         if "pw16" in prof:
             out["roofline"] = gemm_roofline(
-                "pw16", "pw_gemm_f16x3_pre_kernel / pw_gemm_f16x3_kernel (asr_pwconv_mfma_f16x3[_presplit], v_mfma_f32_32x32x16_f16 x3)",
+                "pw16", "pw_gemm_f16x3_pre_kernel / pw_gemm_f16x3_kernel (asr_pwconv_mfma_f16x3[_presplit], v_mfma_f32_16x16x32_f16 x3 / v_mfma_f32_32x32x16_f16 x3)",
                 "pw_gemm_f16x3",
                 round(F16_MFMA_PEAK_TFLOPS / 3.0, 1),
                 "dense f16 MFMA peak 2500 TFLOP/s / 3 MFMA products per f32-grade product")
@@ -331,6 +430,24 @@ def main():
                 "launches": sl, "avg_launch_ms": round(sms / sl, 4),
             }
         out["kernel_time_ms_per_step"] = {k: round(v[0], 3) for k, v in prof.items() if not k.startswith("_")}
+    if rank == 0 and world == 1 and args.precision != "f32" and not args.no_f32_line:
+        # the same workload with every GEMM on the exact-f32 MFMA kernels, a few steps, next to the headline
+        m32, p32 = make_path("f32")
+        m32.engine.shift_logit_bias(CLASS_ID, bias_shift)
+        make_plans(m32)
+        cur["path"] = p32
+        k32 = min(K, 8)
+        run_steps(0, min(Wm, 2) or 1)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run_steps(Wm, k32)
+        torch.cuda.synchronize()
+        e32 = time.perf_counter() - t0
+        out["exact_f32"] = {"value": round(k32 * NUM_AUG / e32, 3), "unit": "augmented-copies/s", "steps": k32,
+                            "ms_per_step": round(1000.0 * e32 / k32, 3),
+                            "note": "--precision f32: every pointwise GEMM on v_mfma_f32_32x32x2_f32, same workload and lanes"}
+        cur["path"] = path
+        del m32, p32
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(weights)
     if rank == 0:

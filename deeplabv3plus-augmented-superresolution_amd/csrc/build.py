@@ -46,9 +46,21 @@ def _stale(target, deps):
 
 
 def build(force=False, verbose=True):
-    hipcc = _hipcc()
+    """Serialised by an exclusive lock on build/.lock: the ranks of one launch may all find the library missing, but only
+    one runs hipcc at a time and the others then find every object up to date."""
+    import fcntl
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
+    with open(os.path.join(objdir, ".lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            return _build_locked(objdir, force, verbose)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(objdir, force, verbose):
+    hipcc = _hipcc()
     hdrs = [os.path.join(HERE, h) for h in HEADERS] + [os.path.abspath(__file__)]
     objs = []
     for src, extra in SOURCES:

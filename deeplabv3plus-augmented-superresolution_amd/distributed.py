@@ -44,9 +44,15 @@ def init_from_env(backend=None):
 
 
 def local_device(local_rank):
-    """cuda:<local_rank>, wrapped onto the visible devices (a rehearsal with more ranks than GPUs shares devices)."""
+    """cuda:<local_rank>.  One rank per GPU is the rule: a LOCAL_RANK beyond the visible devices is an error, except in
+    a declared rehearsal (gloo collectives, ASR_DIST_BACKEND=gloo), where ranks wrap onto the visible devices."""
     n = torch.cuda.device_count()
-    return torch.device("cuda", local_rank % max(n, 1))
+    if local_rank >= n:
+        rehearsal = dist.is_available() and dist.is_initialized() and dist.get_backend() != "nccl"
+        if not rehearsal or n == 0:
+            raise RuntimeError(f"LOCAL_RANK={local_rank} but only {n} device(s) are visible (one rank per GPU)")
+        return torch.device("cuda", local_rank % n)
+    return torch.device("cuda", local_rank)
 
 
 def collective_device(device):

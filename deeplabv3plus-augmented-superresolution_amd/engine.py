@@ -193,6 +193,10 @@ class DeeplabEngine:
         torch.cuda.synchronize(self.device)
         del self._w
 
+    def shift_logit_bias(self, class_id, delta):
+        """Add ``delta`` to the bias of one class of the logits layer (model.py:296-306), in place on the device."""
+        self.p[self.logits_name]["b"][class_id] += float(delta)
+
     # -- plan construction ----------------------------------------------------------------------
     def _build_plan(self, B, H, Wd):
         pool = _Pool(self.device)

@@ -1,6 +1,6 @@
-"""The per-image evaluation loop shared by SR_single_class.py:83-134 and sweep_script.py:96-171 of the reference:
-interchange file -> augmented / max / mean SR -> six IoUs per image -> means.  Images are sharded over the ranks of
-the node (asr_amd.distributed), the per-image records are all-gathered once at the end."""
+"""The per-image evaluation loop of the reference's SR_single_class.py:72-134: interchange file -> augmented / max /
+mean SR -> six IoUs per image -> means over the VALID images.  Images are sharded over the ranks of the node
+(asr_amd.distributed), the per-image records are all-gathered once at the end."""
 from __future__ import annotations
 
 import os
@@ -8,29 +8,49 @@ import os
 import numpy as np
 
 from . import distributed as D
-from .superresolution_scripts.superres_utils import compute_SR, load_SR_data
+from .superresolution_scripts.superres_utils import DATA_EXTS, compute_SR, load_SR_data
 from .utils import compute_IoU, load_image
 
-# wandb.log keys of sweep_script.py:164-171 <- columns of distributed.IOU_FIELDS
-SWEEP_METRICS = {"aug_iou_single": "aug_single", "aug_iou_multiple": "aug_bg", "standard_iou_single": "standard_single",
-                 "standard_iou_multiple": "standard_bg", "mean_iou": "mean", "max_iou": "max"}
+
+
+def interchange_files(root_dir):
+    """Every interchange file under ``root_dir`` in ONE order shared by all ranks: by the integer value of the file stem
+    (VOC-style ids, the order SR_single_class.py:72 asks for with sort=True), names that are not integers after them in
+    lexical order.  os.walk order is file-system dependent, so it is never used as the order."""
+    found = []
+    for folder, _dirs, files in os.walk(root_dir):
+        found += [os.path.join(folder, f) for f in files if f.endswith(DATA_EXTS)]
+
+    def key(path):
+        stem = os.path.basename(path).split(".")[0]
+        return (0, int(stem), path) if stem.isdigit() else (1, 0, path)
+
+    return sorted(found, key=key)
 
 
 def evaluate_precomputed(sr, paths, gt_dir, standard_dir=None, num_aug=100, class_id=8, th_factor=0.65,
                          img_size=(512, 512), out_dir=None, rank=0, world=1, save_final_output=False):
-    """Returns the [len(paths), 6] IoU table (distributed.IOU_FIELDS order; NaN rows for invalid files) on every rank.
-    ``sr.optimizer``'s global step counter is set per image to what the reference's sequential loop would have reached
-    (image_index * num_iter * solves_per_image), so sharding does not change any update."""
+    """Returns the [len(paths), 6] IoU table (distributed.IOU_FIELDS order) on every rank; the row of an invalid file is
+    all-NaN and ``valid_rows`` / ``mean_over_valid`` drop it, like the reference's ``continue`` (SR_single_class.py:85-90).
+    ``sr.optimizer``'s global step counter is set per image to what the reference's sequential loop would have reached:
+    num_iter * solves_per_image * (number of VALID images before it) -- a skipped file runs no solve there, so it does not
+    advance the counter here either.  Validity is a header check every rank can afford for all files, so sharding does not
+    change any update."""
     mine = D.shard_indices(len(paths), rank, world)
+    valid = np.array([_is_valid(p, num_aug) for p in paths], dtype=bool)
+    before = np.concatenate([[0], np.cumsum(valid)[:-1]]) if len(paths) else np.zeros(0, int)
     records = []
     for g in mine:
         try:
+            if not valid[g]:
+                raise Exception(f"File: {paths[g]} is invalid")
             class_masks, max_masks, angles, shifts, filename = load_SR_data(paths[g], num_aug=num_aug)
         except Exception:
             print(f"File: {paths[g]} is invalid, skipping...")
             records.append([np.nan] * len(D.IOU_FIELDS))
             continue
-        sr.optimizer.optimizer.iterations = D.adam_start_step(g, sr.num_iter, "slice_max" if max_masks is not None else "argmax")
+        sr.optimizer.optimizer.iterations = D.adam_start_step(int(before[g]), sr.num_iter,
+                                                              "slice_max" if max_masks is not None else "argmax")
         true_mask = load_image(os.path.join(gt_dir, f"{filename}.png"), image_size=img_size, normalize=False, is_png=True,
                                resize_method="nearest")
         mm = max_masks if max_masks is not None else []
@@ -50,7 +70,27 @@ def evaluate_precomputed(sr, paths, gt_dir, standard_dir=None, num_aug=100, clas
     return D.all_gather_iou(mine, records, len(paths))
 
 
-def sweep_metrics(table):
-    """The dict sweep_script.py:164-171 hands to wandb.log."""
-    m = D.mean_ious(table)
-    return {k: m[v] for k, v in SWEEP_METRICS.items()}
+def _is_valid(path, num_aug):
+    """Cheap validity probe every rank runs over ALL files: the file opens and every array dataset holds >= num_aug
+    entries (superres_utils.py:108-115).  HDF5 files are judged from their object headers alone (no dataset is read)."""
+    from . import hdf5_lite
+    from .superresolution_scripts.superres_utils import _open_SR_file, check_validity
+    try:
+        if str(path).endswith(".npz"):
+            return bool(check_validity(_open_SR_file(path), num_aug=num_aug))
+        shp = hdf5_lite.shapes(path)
+        return "class_masks" in shp and all(len(v) >= 1 and v[0] >= num_aug for k, v in shp.items()
+                                            if k in ("class_masks", "max_masks", "angles", "shifts"))
+    except Exception:
+        return False
+
+
+def valid_rows(table):
+    """Rows of images that were evaluated (an invalid interchange file leaves an all-NaN row)."""
+    table = np.asarray(table, dtype=np.float64)
+    return table[~np.isnan(table).all(axis=1)]
+
+
+def mean_over_valid(table):
+    """The six means SR_single_class.py:129-134 prints: np.mean over the images that were not skipped."""
+    return D.mean_ious(valid_rows(table))

@@ -48,6 +48,7 @@ class _Reader:
         root_entry = off + 32                       # base, free-space, end-of-file, driver-info addresses
         self.root_header = self.u64(root_entry + 8)
         self._gcol = {}
+        self.shapes_only = False
 
     def u16(self, o): return struct.unpack_from("<H", self.b, o)[0]
     def u32(self, o): return struct.unpack_from("<I", self.b, o)[0]
@@ -230,12 +231,23 @@ class _Reader:
         elif cls == 1:
             addr = self.u64(o + 2)
             if addr == UNDEF:                       # never written: the fill value (0)
-                datasets[path] = np.zeros(dims, dt if isinstance(dt, np.dtype) else object)
+                datasets[path] = tuple(dims) if self.shapes_only else np.zeros(dims, dt if isinstance(dt, np.dtype) else object)
                 return
             raw = self.base + addr
         else:
             raise Hdf5Error(f"{path}: chunked datasets are not supported")
-        datasets[path] = self.decode(dt, dims, raw)
+        datasets[path] = tuple(dims) if self.shapes_only else self.decode(dt, dims, raw)
+
+
+def shapes(path):
+    """-> {"group/name": shape tuple} from the object headers alone (the file is memory-mapped; no dataset is read)."""
+    import mmap
+    with open(path, "rb") as f, mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ) as buf:
+        r = _Reader(buf)
+        r.shapes_only = True
+        datasets, attrs = {}, {}
+        r.visit(r.root_header, "", datasets, attrs)
+    return datasets
 
 
 def read(path):

@@ -1,9 +1,8 @@
 """SR glue with the reference's surface (superresolution_scripts/superres_utils.py):
 ``min_max_normalization`` (:56-62), ``threshold_image`` (:118-139), ``load_SR_data`` (:154-210),
-``compute_SR`` (:213-273), ``list_precomputed_data_paths`` / ``check_validity`` for the two-stage
-workflow, and the dataset-list helpers (``get_img_paths`` :9-29, ``class_in_image`` :32-38,
-``filter_images_by_class`` :41-53, ``load_precomputed_images`` :65-78, ``get_precomputed_folders_path`` :81-90,
-``normalize_coefficients`` :142-151).  The interchange file is the reference's HDF5 file (same dataset and
+``compute_SR`` (:213-273) and ``check_hdf5_validity`` (:108-115).  The reference's dataset-list helpers (:9-53,
+:65-105, :142-151) are file plumbing outside the hot path and are not provided; the evaluation loop
+finds its interchange files itself (``asr_amd.evaluation.interchange_files``).  The interchange file is the reference's HDF5 file (same dataset and
 attribute names, written / read by ``hdf5_lite``: files from the reference's h5py writer load here and vice versa);
 an ``.npz`` with the same keys is accepted too (``ASR_DATA_EXT=.npz`` makes it the written format).
 """
@@ -18,63 +17,6 @@ from .. import _lib, hdf5_lite, ops
 
 DATA_EXT = os.environ.get("ASR_DATA_EXT", ".hdf5")          # what save_SR_data writes: ".hdf5" (reference) or ".npz"
 DATA_EXTS = (".hdf5", ".h5", ".npz")                         # what the readers accept
-
-
-def get_img_paths(image_list_path, image_folder, is_png=False, sort=True):
-    """Image identifiers, one per line of ``image_list_path`` -> full paths in ``image_folder``; ``sort`` orders by
-    the integer value of the file stem (VOC ids)."""
-    ext = ".png" if is_png else ".jpg"
-    with open(image_list_path) as fh:
-        paths = [os.path.join(image_folder, line.rstrip() + ext) for line in fh]
-    if sort:
-        paths = sorted(paths, key=lambda p: int(os.path.basename(p).split('.')[0]))
-    return paths
-
-
-def class_in_image(image_path, class_id, image_size=(512, 512)):
-    """True when the ground-truth mask next to ``image_path`` (JPEGImages -> SegmentationClassAug, jpg -> png) has
-    a pixel of ``class_id``."""
-    from ..utils import load_image
-    mask_path = image_path.replace("JPEGImages", "SegmentationClassAug").replace("jpg", "png")
-    mask = load_image(mask_path, image_size=image_size, normalize=False, is_png=True, resize_method="nearest")
-    return bool(np.any(mask == class_id))
-
-
-def filter_images_by_class(path_list, filter_class_id, num_images=None, image_size=(512, 512)):
-    """The first ``num_images`` paths (all when None) whose ground truth contains ``filter_class_id``, in list order."""
-    max_images = num_images if num_images is not None else len(path_list)
-    image_paths = []
-    for path in path_list:
-        if len(image_paths) == max_images:
-            break
-        if class_in_image(path, class_id=filter_class_id, image_size=image_size):
-            image_paths.append(path)
-    return image_paths
-
-
-def load_precomputed_images(img_folder):
-    """PNG copies ``<n>.png`` of a precomputed folder in the order of their integer names (``.npy`` side files skipped)."""
-    from ..utils import load_image
-    names = sorted([n.replace(".png", "") for n in os.listdir(img_folder) if ".npy" not in n], key=int)
-    return [load_image(os.path.join(img_folder, f"{n}.png"), normalize=False, is_png=True) for n in names]
-
-
-def get_precomputed_folders_path(root_dir, num_aug=100):
-    """Sub-folders of ``root_dir`` holding exactly ``num_aug`` copies + 2 side files; others are reported and skipped."""
-    valid_folders = []
-    for path in os.listdir(root_dir):
-        full_path = os.path.join(root_dir, path)
-        if len(os.listdir(full_path)) == (num_aug + 2):
-            valid_folders.append(full_path)
-        else:
-            print(f"Skipped folder named {path} as it is not valid")
-    return valid_folders
-
-
-def normalize_coefficients(coeff_dict):
-    """Same keys, values divided by their sum (threshold_tests.py:91)."""
-    normalizer = np.sum(list(coeff_dict.values()))
-    return {key: (value / normalizer) for (key, value) in coeff_dict.items()}
 
 
 def min_max_normalization(image, new_min=0.0, new_max=255.0, global_min=None, global_max=None):
@@ -136,17 +78,6 @@ def _open_SR_file(filepath):
     out = dict(datasets)
     out.update(attrs.get("/", {}))
     return out
-
-
-def list_precomputed_data_paths(root_dir, sort=False):
-    paths = []
-    for path, _subdirs, files in os.walk(root_dir):
-        for filename in files:
-            if filename.endswith(DATA_EXTS):
-                paths.append(os.path.join(path, filename))
-    if sort:
-        paths = sorted(paths, key=lambda p: int(os.path.basename(p).split('.')[0]))
-    return paths
 
 
 def check_validity(file, num_aug=100):

@@ -31,10 +31,9 @@ def main():
 
     import torch
     from asr_amd import distributed as D
-    from asr_amd.evaluation import evaluate_precomputed
+    from asr_amd.evaluation import evaluate_precomputed, interchange_files, mean_over_valid
     from asr_amd.superresolution_scripts.optimizer import Optimizer
     from asr_amd.superresolution_scripts.superresolution import Superresolution
-    from asr_amd.superresolution_scripts.superres_utils import list_precomputed_data_paths
 
     rank, world, local_rank = D.init_from_env()
     torch.cuda.set_device(local_rank)
@@ -44,11 +43,11 @@ def main():
     sr = Superresolution(lambda_df=HYPER["lambda_df"], lambda_tv=HYPER["lambda_tv"], lambda_L2=HYPER["lambda_L2"],
                          lambda_L1=HYPER["lambda_L1"], num_iter=HYPER["num_iter"], num_aug=args.num_aug,
                          optimizer=optimizer_obj, feature_size=(args.feature_size, args.feature_size))
-    paths = list_precomputed_data_paths(args.data, sort=False)[:args.num_samples]
+    paths = interchange_files(args.data)[:args.num_samples]
     table = evaluate_precomputed(sr, paths, args.gt, args.standard, num_aug=args.num_aug, class_id=args.class_id,
                                  th_factor=args.th_factor, img_size=IMG_SIZE, out_dir=args.out, rank=rank, world=world)
     if rank == 0:
-        m = D.mean_ious(table)
+        m = mean_over_valid(table)
         print(f"Avg. Standard IoUs (No bg): {m['standard_single']},  Avg. Augmented SR IoUs (No bg): {m['aug_single']}")
         print(f"Avg. Standard IoUs (with bg): {m['standard_bg']},  Avg. Augmented SR IoUs (with bg): {m['aug_bg']}")
         print(f"Avg. Max SR IoUs: {m['max']}, Avg. Mean SR IoUs: {m['mean']}")

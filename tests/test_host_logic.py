@@ -124,7 +124,8 @@ def test_interchange_file_roundtrip_and_validity(tmp_path):
     mx = np.random.default_rng(0).random((6, 4, 4, 1)).astype(np.float32)
     a, sh = np.arange(6, dtype=np.float32), np.ones((6, 2), np.float32)
     p = su.save_SR_data(str(tmp_path / "x" / "17"), masks, mx, a, sh, "17", "slice_max", 0.15, 80)
-    assert su.list_precomputed_data_paths(str(tmp_path), sort=True) == [p]
+    from asr_amd.evaluation import interchange_files
+    assert interchange_files(str(tmp_path)) == [p]
     cm, mm, a2, s2, name = su.load_SR_data(p, num_aug=5)
     assert name == "17" and cm.shape == (5, 4, 4, 1) and mm.shape == (5, 4, 4, 1)
     assert cm.max() == 1.0 and cm.min() == 0.0 and mm.max() <= 1.0          # min-max normalised (mode != slice)
@@ -158,31 +159,41 @@ def test_weight_inventory_and_folding():
         W.load_weights("/tmp/definitely_missing_weights.h5")
 
 
-def test_dataset_list_helpers(tmp_path):
-    """superres_utils.py:9-53, 81-90, 142-151: list files, integer-sorted ids, class filter by the sibling mask folder."""
-    from PIL import Image
+def test_evaluation_order_validity_and_means(tmp_path):
+    """SR_single_class.py:72-90,129-134: files in integer order on every rank, an invalid file is skipped -- it does not
+    enter the means and does not advance the optimiser's persistent step counter."""
+    from asr_amd import distributed as D, evaluation as E
     from asr_amd.superresolution_scripts import superres_utils as su
-    jpg, seg = tmp_path / "JPEGImages", tmp_path / "SegmentationClassAug"
-    jpg.mkdir()
-    seg.mkdir()
-    for name, has in (("10", True), ("9", False), ("100", True)):
-        Image.fromarray(np.zeros((8, 8, 3), np.uint8)).save(jpg / f"{name}.jpg")
-        m = np.zeros((8, 8), np.uint8)
-        if has:
-            m[2:4, 2:4] = 8
-        Image.fromarray(m).save(seg / f"{name}.png")
-    lst = tmp_path / "list.txt"
-    lst.write_text("10\n9\n100\n")
-    paths = su.get_img_paths(str(lst), str(jpg), sort=True)
-    assert [os.path.basename(p) for p in paths] == ["9.jpg", "10.jpg", "100.jpg"]
-    assert su.get_img_paths(str(lst), str(seg), is_png=True, sort=False)[0].endswith("10.png")
-    assert su.class_in_image(paths[1], 8, image_size=(8, 8)) and not su.class_in_image(paths[0], 8, image_size=(8, 8))
-    assert [os.path.basename(p) for p in su.filter_images_by_class(paths, 8, num_images=1, image_size=(8, 8))] == ["10.jpg"]
-    n = su.normalize_coefficients({"lambda_tv": 0.84, "lambda_L2": 0.047, "lambda_L1": 0.0065})
-    assert abs(sum(n.values()) - 1.0) < 1e-12 and abs(n["lambda_tv"] - 0.84 / 0.8935) < 1e-12
-    root = tmp_path / "pre"
-    (root / "a").mkdir(parents=True)
-    (root / "b").mkdir()
-    for i in range(4):
-        (root / "a" / f"{i}.png").write_bytes(b"")
-    assert su.get_precomputed_folders_path(str(root), num_aug=2) == [str(root / "a")]
+    masks = np.zeros((6, 4, 4, 1), np.float32)
+    a, sh = np.arange(6, dtype=np.float32), np.ones((6, 2), np.float32)
+    for name, n in (("10", 6), ("9", 6), ("100", 3), ("2007_000032", 6)):
+        su.save_SR_data(str(tmp_path / "d" / name), masks[:n], None, a[:n], sh[:n], name, "argmax", 0.15, 80)
+    (tmp_path / "d" / "11.hdf5").write_bytes(b"not an hdf5 file")
+    paths = E.interchange_files(str(tmp_path))
+    assert [os.path.basename(p) for p in paths] == ["9.hdf5", "10.hdf5", "11.hdf5", "100.hdf5", "2007_000032.hdf5"]
+    valid = [E._is_valid(p, 6) for p in paths]
+    assert valid == [True, True, False, False, True]          # 11: unreadable, 100: only 3 copies
+    table = np.full((5, 6), np.nan)
+    table[[0, 1, 4]] = [[0.5] * 6, [0.7] * 6, [0.9] * 6]
+    assert E.valid_rows(table).shape == (3, 6)
+    m = E.mean_over_valid(table)
+    assert abs(m["aug_single"] - 0.7) < 1e-12 and not any(np.isnan(v) for v in m.values())
+    assert np.isnan(D.mean_ious(table)["aug_single"])         # the plain mean over all rows would be NaN
+
+
+def test_bench_refuses_a_wrong_rank_count():
+    """`bench.py --gpus N` must either start N ranks or fail: a launcher that set WORLD_SIZE to something else, or a box
+    without enough devices, never yields a line that claims N GPUs."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=1 but --gpus 2" in r.stderr and "{" not in r.stdout
+    import torch
+    if torch.cuda.device_count() == 0:
+        env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1"], env=env,
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode != 0 and "no GPU is visible" in r.stderr and "{" not in r.stdout
