@@ -126,7 +126,9 @@ __device__ __forceinline__ void pw_epilogue(const PwArgs& p, f32x16 (&acc)[TM][T
 // pw_epilogue for accumulators of v_mfma_f32_16x16x32_f16: acc[rt][ct] (f32x4) holds rows rt * 16 + 4 * (lane >> 4) + r
 // (r = 0..3), column ct * 16 + (lane & 15) of the wave's (RT * 16) x (CT * 16) sub-tile.  Same LDS transposition, residual
 // prefetch and 16-byte stores as pw_epilogue<..., RES_AHEAD = true>; only the staging map differs.
-template <int WM, int WN, int RT, int CT>
+// RES_LATE (kernels at 168 registers per wave): the residual pieces of a slab are requested AFTER its accumulators have been
+// handed to the LDS (they are dead then), not before -- 64 fewer live registers on the first slab.
+template <int WM, int WN, int RT, int CT, bool RES_LATE = false>
 __device__ __forceinline__ void pw_epilogue16(const PwArgs& p, f32x4 (&acc)[RT][CT], float* smem, int tile_m, int tile_n, int wave, int lane) {
     constexpr int BM = WM * RT * 16, BN = WN * CT * 16, WCOLS = CT * 16;
     constexpr int LPR = WCOLS / 4, RPI = 64 / LPR;
@@ -149,14 +151,17 @@ __device__ __forceinline__ void pw_epilogue16(const PwArgs& p, f32x4 (&acc)[RT][
     for (int i = 0; i < RT / 2; ++i) {                         // 32-row slabs
         const long long m_base = (long long)tile_m * BM + (wm * RT + 2 * i) * 16;
         f32x4 rv[32 / RPI];
-        if (res_vec) {
-            const float* rbase = p.res + (n < p.N ? n : 0);
+        auto request_residual = [&]() {
+            if (res_vec) {
+                const float* rbase = p.res + (n < p.N ? n : 0);
 #pragma unroll
-            for (int q = 0; q < 32 / RPI; ++q) {
-                const long long m = m_base + q * RPI + r_in;
-                rv[q] = *reinterpret_cast<const f32x4*>(rbase + (m < p.M ? m : p.M - 1) * p.ldres);
+                for (int q = 0; q < 32 / RPI; ++q) {
+                    const long long m = m_base + q * RPI + r_in;
+                    rv[q] = *reinterpret_cast<const f32x4*>(rbase + (m < p.M ? m : p.M - 1) * p.ldres);
+                }
             }
-        }
+        };
+        if (!RES_LATE) request_residual();
 #pragma unroll
         for (int h2 = 0; h2 < 2; ++h2)
 #pragma unroll
@@ -168,6 +173,10 @@ __device__ __forceinline__ void pw_epilogue16(const PwArgs& p, f32x4 (&acc)[RT][
                     if (p.relu == 2) v = fminf(v, 6.f);
                     stage[(h2 * 16 + 4 * q4 + r) * WCOLS + ct * 16 + l16] = v;
                 }
+        if (RES_LATE) {
+            __builtin_amdgcn_sched_barrier(0);                 // keep the requests behind the stores that free the accumulators
+            request_residual();
+        }
 #pragma unroll
         for (int q = 0; q < 32 / RPI; ++q) {
             const int r = q * RPI + r_in;
@@ -763,6 +772,127 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void pw_gemm_f16x3_pre_kernel(PwAr
 }
 
 // =================================================================================================
+// Loader-wave form of the pre-split kernel (same 256 x 256 tile, same two 64 KB LDS stages, same MFMA sequence per
+// accumulator => bit-identical results).  The phase profile of pw_gemm_f16x3_pre_kernel shows the matrix pipe idle for the
+// ~1000 cycles per K-step in which all eight waves sit in the vector-memory issue queue requesting the next stage (a wave
+// pays ~150 cycles per 1 KiB LDS-DMA piece whoever issues it, and a wave that is issuing cannot issue MFMAs).  Here
+// the twelve waves of the workgroup have fixed roles: waves 0-7 only read fragments and issue MFMAs (they never execute a
+// vector-memory instruction inside the K loop), waves 8-11 -- one per SIMD -- only request: 16 pieces each per K-step
+// (~2400 cycles of issue, under the 3100 cycles the two MFMA waves of the SIMD need), then wait for their landing and
+// meet the MFMA waves at the K-step's barrier.  Three waves per SIMD leave 168 registers per wave: the MFMA waves hold
+// the 128 accumulators and walk their 64 x 128 tile in two 32-row halves (A fragments of two row tiles at a time, the B
+// fragments are read once per half).
+// =================================================================================================
+template <int PIECES_PER_LOADER = 16>
+__global__ __launch_bounds__(768, 3) void pw_gemm_f16x3_pre_lw_kernel(PwArgs p) {
+    constexpr int BM = 256, BN = 256, WN = 2, RT = 4, CT = 8;
+    constexpr int A_BYTES = BM * 128, B_BYTES = 4 * BN * 16, STAGE_BYTES = A_BYTES + 2 * B_BYTES;
+    constexpr int A_PIECES = A_BYTES / 1024;                   // 32 pieces of 64 lanes x 16 B; then 32 B pieces (hi plane, lo plane)
+    static_assert(4 * PIECES_PER_LOADER * 1024 == STAGE_BYTES, "four loader waves cover one stage");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    char* const lds = reinterpret_cast<char*>(smem);
+
+    const int nwg = gridDim.x, orig = blockIdx.x;
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
+    const int lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+    const int tile_m = lid / p.tiles_n, tile_n = lid % p.tiles_n;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int KT = p.Kpad / BK;
+
+    if (wave >= 8) {
+        // ---- loader wave: pieces (wave - 8) * 16 .. + 15 of every stage ------------------------------------------
+        const int first = (wave - 8) * PIECES_PER_LOADER;
+        const char* src[PIECES_PER_LOADER];
+        long long kstep[2];                                     // byte advance per K-step: A pieces, B pieces
+        kstep[0] = 128;
+        kstep[1] = (long long)4 * p.Npad * 16;
+        const long long plane_bytes = (long long)p.Kpad * p.Npad * 2;
+#pragma unroll
+        for (int j = 0; j < PIECES_PER_LOADER; ++j) {
+            const int pi = first + j;
+            if (pi < A_PIECES) {                                // A: (row q >> 3, LDS slot q & 7 holding global slot ^ swizzle)
+                const int q = pi * 64 + lane, row = q >> 3, slot = (q & 7) ^ ((row >> 1) & 7);
+                long long m = (long long)tile_m * BM + row;
+                if (m >= p.M) m = p.M - 1;                      // rows past the end re-read the last row; never stored
+                src[j] = reinterpret_cast<const char*>(p.x) + (m * p.ldx) * 128 + slot * 16;
+            } else {                                            // B: plane (hi, lo), k-octet, column
+                const int qb = (pi - A_PIECES) * 64 + lane, plane = qb >> 10, r = qb & 1023, oct = r >> 8, col = r & 255;
+                src[j] = reinterpret_cast<const char*>(p.wp) + plane * plane_bytes +
+                         (((long long)oct * p.Npad) + (long long)tile_n * BN + col) * 16;
+            }
+        }
+        auto issue = [&](int kt, int stage) {
+            char* const st = lds + stage * STAGE_BYTES + first * 1024;
+#pragma unroll
+            for (int j = 0; j < PIECES_PER_LOADER; ++j)
+                glds16(src[j] + kt * kstep[(first + j) < A_PIECES ? 0 : 1], st + j * 1024);
+        };
+        issue(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        for (int kt = 0; kt < KT; ++kt) {
+            if (kt + 1 < KT) issue(kt + 1, (kt + 1) & 1);      // the other stage: last read before the previous barrier
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // landed before anyone is released to read it
+            __builtin_amdgcn_s_barrier();
+        }
+        return;
+    }
+
+    // ---- MFMA wave ------------------------------------------------------------------------------------------------
+    const int wm = wave / WN, wn = wave % WN;
+    const int l16 = lane & 15, oct = lane >> 4;                // A: row = l16, k = 8 oct ..; B: column = l16, same k
+    f32x4 acc[RT][CT];
+#pragma unroll
+    for (int i = 0; i < RT; ++i)
+#pragma unroll
+        for (int j = 0; j < CT; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
+
+    __builtin_amdgcn_s_barrier();                              // stage 0 landed (the loaders waited for it)
+    for (int kt = 0; kt < KT; ++kt) {
+        const char* const st = lds + (kt & 1) * STAGE_BYTES;
+        // 2 halves x 8 column tiles = 16 groups of 6 MFMAs; the fragments of group g + 1 are requested before the MFMAs of
+        // group g (one B double buffer, the A pair of the second half is requested under the last group of the first),
+        // and a scheduling barrier per group keeps the compiler from hoisting every read to the top (it would need 160
+        // fragment registers and spill).
+        f16x8 ah[2][2], al[2][2], bh[2], bl[2];
+        auto read_a = [&](int half, int buf) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int row = (wm * RT + 2 * half + i) * 16 + l16, swz = (row >> 1) & 7;
+                ah[buf][i] = *reinterpret_cast<const f16x8*>(st + row * 128 + ((oct ^ swz) << 4));
+                al[buf][i] = *reinterpret_cast<const f16x8*>(st + row * 128 + (((4 + oct) ^ swz) << 4));
+            }
+        };
+        auto read_b = [&](int j, int buf) {
+            const int col = (wn * CT + j) * 16 + l16;
+            bh[buf] = *reinterpret_cast<const f16x8*>(st + A_BYTES + (oct * BN + col) * 16);
+            bl[buf] = *reinterpret_cast<const f16x8*>(st + A_BYTES + B_BYTES + (oct * BN + col) * 16);
+        };
+        read_a(0, 0);
+        read_b(0, 0);
+#pragma unroll
+        for (int g = 0; g < 2 * CT; ++g) {
+            const int half = g / CT, j = g % CT;
+            if (g + 1 < 2 * CT) read_b((g + 1) % CT, (g + 1) & 1);
+            if (g == CT - 1) read_a(1, 1);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                f32x4& a4 = acc[2 * half + i][j];
+                a4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[half][i], bh[g & 1], a4, 0, 0, 0);
+                a4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[half][i], bl[g & 1], a4, 0, 0, 0);
+                a4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[half][i], bh[g & 1], a4, 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // this wave's reads of the stage are done
+        __builtin_amdgcn_s_barrier();
+    }
+    if (!(p.debug & 1)) pw_epilogue16<4, WN, RT, CT, true>(p, acc, smem, tile_m, tile_n, wave, lane);
+}
+
+// =================================================================================================
 // Three-stage form of the pre-split kernel: 256 x 128 tile (8 waves of 64 x 64, 16 v_mfma_f32_16x16x32_f16 tiles each),
 // three 48 KB LDS stages, the DMA requests run TWO K-steps ahead, and the two waves that share a SIMD take opposite
 // orders: waves 0-3 request their 6 pieces of K-step kt + 2 BEFORE their 48 MFMAs of K-step kt, waves 4-7 AFTER theirs.
@@ -1145,6 +1275,17 @@ extern "C" int asr_pwconv_mfma_f16x3_presplit(const void* x_split, const float* 
     constexpr size_t lds = 2 * (bm * 128 + 2 * 4 * bn * 16);
     // (a persistent one-workgroup-per-CU form that requests the next output tile's first K tile before the epilogue of the
     // current one, staging the epilogue through a single LDS stage, measured equal: -2 % .. +4 %; not kept)
+    static const bool lw = getenv("ASR_PRE_LW") && atoi(getenv("ASR_PRE_LW")) == 1;
+    if (lw) {
+        static bool attr_lw = false;
+        if (!attr_lw) {
+            ASR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pw_gemm_f16x3_pre_lw_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr_lw = true;
+        }
+        hipLaunchKernelGGL(pw_gemm_f16x3_pre_lw_kernel<16>, dim3((unsigned)nwg), dim3(768), lds, asr_stream(stream), a);
+        ASR_LAUNCH_CHECK();
+        return ASR_OK;
+    }
     // ASR_PRE_MFMA=32: the v_mfma_f32_32x32x16_f16 form (bit-identical to the in-kernel-split kernel) instead of 16x16x32
     static const bool m32 = getenv("ASR_PRE_MFMA") && atoi(getenv("ASR_PRE_MFMA")) == 32;
     auto kern = m32 ? pw_gemm_f16x3_pre_kernel<4, 2, 2, 4, false> : pw_gemm_f16x3_pre_kernel<4, 2, 2, 4, true>;

@@ -9,6 +9,10 @@ features as the output, model.py:100-106).
 """
 from __future__ import annotations
 
+import os
+import sys
+import warnings
+
 import numpy as np
 import torch
 
@@ -56,12 +60,22 @@ class DeeplabV3Plus:
         decoder = "full"
         if self.backbone == "xception":
             decoder = "dcnn" if only_DCNN_output else ("aspp" if only_ASPP_output else "full")
-        if self.load_weights and self.weights_path is not None:
-            params = W.load_weights(self.weights_path)          # local file only (never the URL of model.py:9)
-        else:
-            # The pretrained .h5 is a network download (model.py:134-143): unavailable offline.
-            params = W.make_synthetic_weights(self.synthetic_seed, self.classes, backbone=self.backbone, alpha=self.alpha,
-                                              decoder=decoder, class_prediction=final_class_prediction)
+        # Seeded initialisation of the whole inventory: what Keras holds before load_weights (random init there).
+        params = W.make_synthetic_weights(self.synthetic_seed, self.classes, backbone=self.backbone, alpha=self.alpha,
+                                          decoder=decoder, class_prediction=final_class_prediction)
+        path = self.weights_path or os.environ.get("ASR_WEIGHTS")
+        if self.load_weights and path:
+            # local file only (never the URL of model.py:9); by_name=True, skip_mismatch=True like model.py:145
+            params, skipped = W.merge_by_name(params, W.load_weights(path))
+            for name, why in skipped:
+                print(f"asr_amd: layer variable {name} not loaded from {path} ({why}); keeping its seeded initialisation",
+                      file=sys.stderr)
+        elif self.load_weights:
+            # The reference would download the pretrained .h5 here (model.py:134-143): unavailable offline.
+            warnings.warn("DeeplabV3Plus(load_weights=True) without weights_path / $ASR_WEIGHTS: the pretrained checkpoint is a "
+                          "network download in the reference and is NOT available here -- running on SEEDED SYNTHETIC "
+                          "weights; masks and IoUs are meaningless as segmentation results (pass load_weights=False to "
+                          "say so explicitly).", RuntimeWarning, stacklevel=2)
         return DeeplabModel(params, self.input_shape, self.classes, final_upsample, self.last_activation,
                             precision=self.precision, backbone=self.backbone, alpha=self.alpha, OS=self.OS,
                             reshape_outputs=self.reshape_outputs, decoder=decoder, first_upsample_size=first_upsample_size,

@@ -240,6 +240,25 @@ def load_weights(path):
         return {k: z[k] for k in z.files}
 
 
+def merge_by_name(template, loaded):
+    """Keras ``load_weights(by_name=True, skip_mismatch=True)`` (model.py:145) on ``{layer}/{variable}`` dictionaries:
+    every variable of ``template`` (the model's own inventory, already initialised) takes the loaded array of the same
+    name when its shape matches; a missing or mismatched variable keeps its initial value and is reported.  Loaded
+    entries the model has no layer for are ignored, as Keras does.  Returns (params, [(name, reason)])."""
+    out, skipped = {}, []
+    for name, init in template.items():
+        got = loaded.get(name)
+        if got is None:
+            out[name] = init
+            skipped.append((name, "absent from the file"))
+        elif tuple(np.shape(got)) != tuple(init.shape):
+            out[name] = init
+            skipped.append((name, f"shape {tuple(np.shape(got))} != {tuple(init.shape)}"))
+        else:
+            out[name] = np.asarray(got, dtype=np.float32)
+    return out, skipped
+
+
 def bn_scale_shift(weights, name, eps):
     g = weights[name + "/gamma"].astype(np.float32)
     b = weights[name + "/beta"].astype(np.float32)

@@ -94,9 +94,13 @@ def test_final_upsample_matches_oracle(dev, synthetic):
     np.testing.assert_allclose(flat, ref_sm.reshape(1, 64 * 64, 21), rtol=0, atol=2e-5)
 
 
-def test_hot_path_config1_test_cat(dev, synthetic, golden_dir, tmp_path):
-    """test_SR.py flow on the bundled sample at 256x256 (oracle-sized): same seed -> same
-    angles/shifts; masks from the HIP path vs the oracle path; IoU within 1e-3 (north_star bar)."""
+@pytest.mark.parametrize("side,fside,iters,shift_max", [(256, 64, 20, 40), (512, 128, 50, 80)],
+                         ids=["256-reduced", "512-configs0-full-size"])
+def test_hot_path_config1_test_cat(dev, synthetic, golden_dir, tmp_path, side, fside, iters, shift_max):
+    """test_SR.py:57-97 on the bundled sample through the reference-shaped API: same seed -> same angles/shifts; masks
+    from the HIP path vs the oracle path; IoU within 1e-3 (north_star bar).  The 512 case is BASELINE configs[0] exactly
+    as stated (test_cat at 512x512, 128x128 features, num_aug=8, argmax OPM, class 8, angle 0.15 / shift 80 of
+    test_SR.py:20-47) with 50 AMSGrad iterations; the 256 case is the quick reduced form."""
     from asr_amd.model import DeeplabModel
     from asr_amd.utils import load_image, compute_IoU
     from asr_amd.superresolution_scripts.optimizer import Optimizer
@@ -106,7 +110,7 @@ def test_hot_path_config1_test_cat(dev, synthetic, golden_dir, tmp_path):
 
     img_path = os.path.join(golden_dir, "test_cat.jpg")
     gt_path = os.path.join(golden_dir, "test_cat_gt.png")
-    size, fsize, n_aug, cls, iters = (256, 256), (64, 64), 8, 8, 20
+    size, fsize, n_aug, cls = (side, side), (fside, fside), 8, 8
 
     # ---- HIP path through the reference-shaped API ----
     np.random.seed(1234)
@@ -115,7 +119,7 @@ def test_hot_path_config1_test_cat(dev, synthetic, golden_dir, tmp_path):
     sr = Superresolution(1.0, 0.3, 0.7, 0.0, num_iter=iters, num_aug=n_aug, optimizer=opt, feature_size=fsize,
                          output_size=size)
     masks, max_masks, angles, shifts, name = compute_augmented_feature_maps(
-        img_path, model, filter_class_id=cls, mode="argmax", num_aug=n_aug, angle_max=0.15, shift_max=40,
+        img_path, model, filter_class_id=cls, mode="argmax", num_aug=n_aug, angle_max=0.15, shift_max=shift_max,
         image_size=size, batch_size=4)
     assert name == "test_cat" and len(masks) == n_aug and masks[0].shape == fsize + (1,)
     out = {t: compute_SR(sr, masks, angles, shifts, name, str(tmp_path), SR_type=t, max_masks=max_masks,
@@ -125,7 +129,7 @@ def test_hot_path_config1_test_cat(dev, synthetic, golden_dir, tmp_path):
     # ---- oracle path, same seed ----
     np.random.seed(1234)
     o_img = o_aug.load_image(img_path, image_size=size)
-    o_copies, o_angles, o_shifts = o_aug.create_augmented_copies(o_img, n_aug, 0.15, 40)
+    o_copies, o_angles, o_shifts = o_aug.create_augmented_copies(o_img, n_aug, 0.15, shift_max)
     assert np.array_equal(o_angles, angles) and np.array_equal(o_shifts, shifts)
     o_pred = OracleDeeplabV3Plus(synthetic).predict(o_copies, batch_size=4)
     o_masks, _ = o_aug.opm(o_pred, cls, "argmax")
@@ -139,7 +143,8 @@ def test_hot_path_config1_test_cat(dev, synthetic, golden_dir, tmp_path):
     for t in ("aug", "max", "mean"):
         ref = o_sr.compute_SR(o_srobj, o_masks, o_angles, o_shifts, SR_type=t, class_id=cls, th_factor=0.2)
         # mask-vs-mask IoU (identical augmentation seeds) and IoU-vs-GT delta, both within 1e-3
-        assert o_aug.single_class_IOU(ref, out[t], cls, False) >= 0.999 or (ref == cls).sum() == 0
+        assert (ref == cls).any(), t                   # class 8 must be present: an empty mask would compare vacuously
+        assert o_aug.single_class_IOU(ref, out[t], cls, False) >= 0.999, t
         d = abs(np.nan_to_num(compute_IoU(gt, out[t], img_size=size, class_id=cls)) -
                 np.nan_to_num(o_aug.compute_IoU(o_gt, ref, img_size=size, class_id=cls)))
         assert d <= 1e-3, (t, d)

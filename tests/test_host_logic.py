@@ -197,3 +197,21 @@ def test_bench_refuses_a_wrong_rank_count():
         r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1"], env=env,
                            capture_output=True, text=True, timeout=300)
         assert r.returncode != 0 and "no GPU is visible" in r.stderr and "{" not in r.stdout
+
+
+def test_weights_merge_by_name_skips_mismatches():
+    """model.py:145 load_weights(by_name=True, skip_mismatch=True): matching variables are taken, a missing layer or a
+    shape mismatch (e.g. a 5-class logits layer against a 21-class checkpoint) keeps the initial value and is reported."""
+    from asr_amd import weights as W
+    tmpl = W.make_synthetic_weights(7, 5)
+    ckpt = W.make_synthetic_weights(8, 21)
+    del ckpt["aspp0_BN/gamma"]
+    ckpt["not_a_layer/kernel"] = np.zeros((1, 1, 2, 2), np.float32)
+    merged, skipped = W.merge_by_name(tmpl, ckpt)
+    names = dict(skipped)
+    assert set(merged) == set(tmpl)
+    assert "absent" in names["aspp0_BN/gamma"] and np.array_equal(merged["aspp0_BN/gamma"], tmpl["aspp0_BN/gamma"])
+    assert set(names) == {"aspp0_BN/gamma", "custom_logits_semantic/kernel", "custom_logits_semantic/bias"}
+    assert np.array_equal(merged["entry_flow_conv1_1/kernel"], ckpt["entry_flow_conv1_1/kernel"])
+    same, none = W.merge_by_name(ckpt, dict(ckpt))
+    assert none == [] and all(np.array_equal(same[k], ckpt[k]) for k in ckpt if k != "not_a_layer/kernel")
