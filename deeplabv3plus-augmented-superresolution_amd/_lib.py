@@ -12,7 +12,8 @@ import os
 import torch
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG_DIR, "libasr_hip.so")
+# ASR_LIB selects another build of the same ABI (a diagnostic variant of csrc/build.py); default: the product library
+LIB_PATH = os.environ.get("ASR_LIB") or os.path.join(_PKG_DIR, "libasr_hip.so")
 
 ASR_OK = 0
 

@@ -14,6 +14,10 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
 LIB = os.path.join(PKG, "libasr_hip.so")
+# Diagnostic builds never replace the product library: `ASR_BUILD_VARIANT=phase` (s_memtime phase stamps in the GEMM K
+# loops, a device synchronisation after every split-f16 launch) goes to its own object directory and library; select it at
+# run time with ASR_LIB=<path> (asr_amd/_lib.py).
+VARIANTS = {"phase": ["-DASR_GEMM_PHASE_PROFILE"]}
 
 # (source, extra flags)
 SOURCES = [
@@ -49,18 +53,28 @@ def build(force=False, verbose=True):
     """Serialised by an exclusive lock on build/.lock: the ranks of one launch may all find the library missing, but only
     one runs hipcc at a time and the others then find every object up to date."""
     import fcntl
-    objdir = os.path.join(HERE, "build")
+    variant = os.environ.get("ASR_BUILD_VARIANT", "")
+    if variant and variant not in VARIANTS:
+        raise ValueError(f"ASR_BUILD_VARIANT must be one of {sorted(VARIANTS)} (got {variant!r})")
+    objdir = os.path.join(HERE, "build_" + variant if variant else "build")
     os.makedirs(objdir, exist_ok=True)
     with open(os.path.join(objdir, ".lock"), "w") as lock:
         fcntl.flock(lock, fcntl.LOCK_EX)
         try:
-            return _build_locked(objdir, force, verbose)
+            return _build_locked(objdir, force, verbose, variant)
         finally:
             fcntl.flock(lock, fcntl.LOCK_UN)
 
 
-def _build_locked(objdir, force, verbose):
+def _build_locked(objdir, force, verbose, variant=""):
     hipcc = _hipcc()
+    lib = os.path.join(PKG, f"libasr_hip_{variant}.so") if variant else LIB
+    extra_all = VARIANTS.get(variant, []) + os.environ.get("ASR_EXTRA_HIPFLAGS", "").split()
+    # the flag set is part of the staleness key: objects built with other flags are rebuilt
+    stamp = os.path.join(objdir, "flags.txt")
+    flags_now = " ".join(COMMON + extra_all)
+    if not os.path.exists(stamp) or open(stamp).read() != flags_now:
+        force = True
     hdrs = [os.path.join(HERE, h) for h in HEADERS] + [os.path.abspath(__file__)]
     objs = []
     for src, extra in SOURCES:
@@ -68,18 +82,19 @@ def _build_locked(objdir, force, verbose):
         o = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
         objs.append(o)
         if force or _stale(o, [s] + hdrs):
-            cmd = [hipcc] + COMMON + extra + os.environ.get("ASR_EXTRA_HIPFLAGS", "").split() + ["-c", s, "-o", o]
+            cmd = [hipcc] + COMMON + extra + extra_all + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)
-    if force or _stale(LIB, objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    if force or _stale(lib, objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
-    return LIB
+    with open(stamp, "w") as fh:
+        fh.write(flags_now)
+    return lib
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
-    print(LIB)
+    print(build(force="--force" in sys.argv))

@@ -21,6 +21,7 @@
 //    (private L2), using the bijective remap.
 #include "asr_common.h"
 #include <stdlib.h>
+#include <utility>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -126,9 +127,9 @@ __device__ __forceinline__ void pw_epilogue(const PwArgs& p, f32x16 (&acc)[TM][T
 // pw_epilogue for accumulators of v_mfma_f32_16x16x32_f16: acc[rt][ct] (f32x4) holds rows rt * 16 + 4 * (lane >> 4) + r
 // (r = 0..3), column ct * 16 + (lane & 15) of the wave's (RT * 16) x (CT * 16) sub-tile.  Same LDS transposition, residual
 // prefetch and 16-byte stores as pw_epilogue<..., RES_AHEAD = true>; only the staging map differs.
-// RES_LATE (kernels at 168 registers per wave): the residual pieces of a slab are requested AFTER its accumulators have been
-// handed to the LDS (they are dead then), not before -- 64 fewer live registers on the first slab.
-template <int WM, int WN, int RT, int CT, bool RES_LATE = false>
+// RES_INLINE (kernels at 168 registers per wave): no residual prefetch -- each residual piece is loaded where it is added, so
+// the 64 registers of the prefetch queue are free for the accumulators of the slabs still waiting.
+template <int WM, int WN, int RT, int CT, bool RES_INLINE = false>
 __device__ __forceinline__ void pw_epilogue16(const PwArgs& p, f32x4 (&acc)[RT][CT], float* smem, int tile_m, int tile_n, int wave, int lane) {
     constexpr int BM = WM * RT * 16, BN = WN * CT * 16, WCOLS = CT * 16;
     constexpr int LPR = WCOLS / 4, RPI = 64 / LPR;
@@ -161,7 +162,7 @@ __device__ __forceinline__ void pw_epilogue16(const PwArgs& p, f32x4 (&acc)[RT][
                 }
             }
         };
-        if (!RES_LATE) request_residual();
+        if (!RES_INLINE) request_residual();
 #pragma unroll
         for (int h2 = 0; h2 < 2; ++h2)
 #pragma unroll
@@ -173,10 +174,6 @@ __device__ __forceinline__ void pw_epilogue16(const PwArgs& p, f32x4 (&acc)[RT][
                     if (p.relu == 2) v = fminf(v, 6.f);
                     stage[(h2 * 16 + 4 * q4 + r) * WCOLS + ct * 16 + l16] = v;
                 }
-        if (RES_LATE) {
-            __builtin_amdgcn_sched_barrier(0);                 // keep the requests behind the stores that free the accumulators
-            request_residual();
-        }
 #pragma unroll
         for (int q = 0; q < 32 / RPI; ++q) {
             const int r = q * RPI + r_in;
@@ -184,7 +181,7 @@ __device__ __forceinline__ void pw_epilogue16(const PwArgs& p, f32x4 (&acc)[RT][
             f32x4 v = *reinterpret_cast<const f32x4*>(stage + r * WCOLS + c4 * 4);
             if (m < p.M && n < p.N) {
                 if (vec_ok) {
-                    if (p.res) v += rv[q];
+                    if (p.res) v += RES_INLINE ? *reinterpret_cast<const f32x4*>(p.res + m * p.ldres + n) : rv[q];
                     *reinterpret_cast<f32x4*>(p.y + m * p.ldy + n) = v;
                 } else {
 #pragma unroll
@@ -386,7 +383,7 @@ __device__ __forceinline__ void split_f16x8(const f32x4& a, const f32x4& b, f16x
 // wave 0 of every block accumulates shader-clock deltas per phase and the launcher prints their means.
 #ifdef ASR_GEMM_PHASE_PROFILE
 #define ASR_PHASE_BLOCKS 8192
-__device__ long long g_phase_cycles[ASR_PHASE_BLOCKS * 8];
+__device__ long long g_phase_cycles[ASR_PHASE_BLOCKS * 16];    // per block: 0-7 wave 0's phases, 8-10 loader wave, 11/12 K-loop cycles / 100 MHz ticks
 #define PHASE_MARK(i)                                              \
     do {                                                           \
         const long long now_ = (long long)__builtin_readcyclecounter(); \
@@ -600,7 +597,7 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void pw_gemm_f16x3_kernel(PwArg
 #ifdef ASR_GEMM_PHASE_PROFILE
     PHASE_MARK(7);                                             // epilogue
     if (tid == 0 && orig < ASR_PHASE_BLOCKS)
-        for (int i = 0; i < 8; ++i) g_phase_cycles[orig * 8 + i] = ph[i];
+        for (int i = 0; i < 8; ++i) g_phase_cycles[orig * 16 + i] = ph[i];
 #endif
 }
 
@@ -622,7 +619,10 @@ __device__ __forceinline__ void glds16(const void* g, void* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((asr_gbl_ptr)g, (asr_lds_ptr)lds_wave_base, 16, 0, 0);
 }
 
-template <int WM, int WN, int TM, int TN, bool M16>
+// HL ("half load"): only the second-dispatched half of the waves (4-7, the SIMD partners that lose the matrix-pipe
+// arbitration to waves 0-3 anyway) requests the next stage -- 16 pieces each, their own and their partner's -- while waves
+// 0-3 go straight to their MFMAs; waves 4-7 run their MFMAs when the pipe frees up.
+template <int WM, int WN, int TM, int TN, bool M16, bool HL = false>
 __global__ __launch_bounds__(WM * WN * 64, 2) void pw_gemm_f16x3_pre_kernel(PwArgs p) {
     constexpr int NT = WM * WN * 64, BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int A_BYTES = BM * 128, B_BYTES = 4 * BN * 16, STAGE_BYTES = A_BYTES + 2 * B_BYTES;
@@ -635,36 +635,48 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void pw_gemm_f16x3_pre_kernel(PwAr
     const int q8 = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
     const int lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
     const int tile_m = lid / p.tiles_n, tile_n = lid % p.tiles_n;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
     const int l32 = lane & 31, hh = lane >> 5;
 
-    // per-thread DMA sources: A piece q = tid + NT * i -> (row q >> 3, LDS slot q & 7, holding global slot ^ swizzle)
-    const char* a_src[PA];
-#pragma unroll
-    for (int i = 0; i < PA; ++i) {
-        const int q = tid + NT * i, row = q >> 3, slot = (q & 7) ^ ((row >> 1) & 7);
-        long long m = (long long)tile_m * BM + row;
-        if (m >= p.M) m = p.M - 1;                             // rows past the end re-read the last row; never stored
-        a_src[i] = reinterpret_cast<const char*>(p.x) + (m * p.ldx) * 128 + slot * 16;   // + kt * 128 per K chunk
-    }
+    // per-thread DMA sources: A piece q = slot_wave * 64 + lane + NT * i -> (row q >> 3, LDS slot q & 7, holding global
+    // slot ^ swizzle); a wave requests the pieces of NS wave slots (HL: its partner's and its own)
+    constexpr int NS = HL ? 2 : 1;
+    const bool requester = !HL || wave >= WM * WN / 2;
+    const char* a_src[NS][PA];
+    const char* b_src[NS][PB];
+    int slot_wave[NS];
     const long long plane_bytes = (long long)p.Kpad * p.Npad * 2;
-    const char* b_src[PB];
 #pragma unroll
-    for (int i = 0; i < PB; ++i) {
-        const int q = tid + NT * i, oct = q / BN, col = q % BN;
-        b_src[i] = reinterpret_cast<const char*>(p.wp) + (((long long)oct * p.Npad) + (long long)tile_n * BN + col) * 16;  // + kt * 4 * Npad * 16
+    for (int sl = 0; sl < NS; ++sl) {
+        slot_wave[sl] = HL ? ((wave & (WM * WN / 2 - 1)) + sl * (WM * WN / 2)) : wave;
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+            const int q = slot_wave[sl] * 64 + lane + NT * i, row = q >> 3, slot = (q & 7) ^ ((row >> 1) & 7);
+            long long m = (long long)tile_m * BM + row;
+            if (m >= p.M) m = p.M - 1;                         // rows past the end re-read the last row; never stored
+            a_src[sl][i] = reinterpret_cast<const char*>(p.x) + (m * p.ldx) * 128 + slot * 16;   // + kt * 128 per K chunk
+        }
+#pragma unroll
+        for (int i = 0; i < PB; ++i) {
+            const int q = slot_wave[sl] * 64 + lane + NT * i, oct = q / BN, col = q % BN;
+            b_src[sl][i] = reinterpret_cast<const char*>(p.wp) + (((long long)oct * p.Npad) + (long long)tile_n * BN + col) * 16;  // + kt * 4 * Npad * 16
+        }
     }
     const long long b_kstep = (long long)4 * p.Npad * 16;
 
     auto issue_tile = [&](int kt, int stage) {
+        if (!requester) return;
         char* const st = lds + stage * STAGE_BYTES;
 #pragma unroll
-        for (int i = 0; i < PA; ++i) glds16(a_src[i] + (long long)kt * 128, st + (wave * 64 + NT * i) * 16);
+        for (int sl = 0; sl < NS; ++sl) {
 #pragma unroll
-        for (int i = 0; i < PB; ++i) {
-            glds16(b_src[i] + kt * b_kstep, st + A_BYTES + (wave * 64 + NT * i) * 16);
-            glds16(b_src[i] + kt * b_kstep + plane_bytes, st + A_BYTES + B_BYTES + (wave * 64 + NT * i) * 16);
+            for (int i = 0; i < PA; ++i) glds16(a_src[sl][i] + (long long)kt * 128, st + (slot_wave[sl] * 64 + NT * i) * 16);
+#pragma unroll
+            for (int i = 0; i < PB; ++i) {
+                glds16(b_src[sl][i] + kt * b_kstep, st + A_BYTES + (slot_wave[sl] * 64 + NT * i) * 16);
+                glds16(b_src[sl][i] + kt * b_kstep + plane_bytes, st + A_BYTES + B_BYTES + (slot_wave[sl] * 64 + NT * i) * 16);
+            }
         }
     };
 
@@ -698,6 +710,9 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void pw_gemm_f16x3_pre_kernel(PwAr
     issue_tile(0, 0);
     __syncthreads();                                           // drains the DMA (vmcnt(0)) and publishes stage 0
     PHASE_MARK(0);
+#ifdef ASR_GEMM_PHASE_PROFILE
+    const long long loop_c0 = (long long)__builtin_readcyclecounter(), loop_r0 = (long long)__builtin_amdgcn_s_memrealtime();
+#endif
     for (int kt = 0; kt < KT; ++kt) {
         const char* const st = lds + (kt & 1) * STAGE_BYTES;
         // All 8 DMA pieces of the next tile go out before the MFMAs (spreading them between the MFMA groups, or letting
@@ -757,6 +772,12 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void pw_gemm_f16x3_pre_kernel(PwAr
         __syncthreads();                                       // next stage landed (vmcnt(0)) and everyone is done reading this one
         PHASE_MARK(6);
     }
+#ifdef ASR_GEMM_PHASE_PROFILE
+    if (tid == 0 && orig < ASR_PHASE_BLOCKS) {
+        g_phase_cycles[orig * 16 + 11] = (long long)__builtin_readcyclecounter() - loop_c0;
+        g_phase_cycles[orig * 16 + 12] = (long long)__builtin_amdgcn_s_memrealtime() - loop_r0;
+    }
+#endif
     if (M16) {
         if (!(p.debug & 1)) pw_epilogue16<WM, WN, (M16 ? 2 * TM : 2), (M16 ? 2 * TN : 1)>(p, reinterpret_cast<f32x4(&)[M16 ? 2 * TM : 2][M16 ? 2 * TN : 1]>(acc16), smem, tile_m, tile_n, wave, lane);
     } else {
@@ -767,7 +788,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void pw_gemm_f16x3_pre_kernel(PwAr
     PHASE_WAIT_VM();
     PHASE_MARK(7);
     if (tid == 0 && orig < ASR_PHASE_BLOCKS)
-        for (int i = 0; i < 8; ++i) g_phase_cycles[orig * 8 + i] = ph[i];
+        for (int i = 0; i < 8; ++i) g_phase_cycles[orig * 16 + i] = ph[i];
 #endif
 }
 
@@ -783,6 +804,15 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void pw_gemm_f16x3_pre_kernel(PwAr
 // the 128 accumulators and walk their 64 x 128 tile in two 32-row halves (A fragments of two row tiles at a time, the B
 // fragments are read once per half).
 // =================================================================================================
+template <typename F, int... I>
+__device__ __forceinline__ void asr_static_for_impl(F& f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void asr_static_for(F& f) {
+    asr_static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
 template <int PIECES_PER_LOADER = 16>
 __global__ __launch_bounds__(768, 3) void pw_gemm_f16x3_pre_lw_kernel(PwArgs p) {
     constexpr int BM = 256, BN = 256, WN = 2, RT = 4, CT = 8;
@@ -830,11 +860,22 @@ __global__ __launch_bounds__(768, 3) void pw_gemm_f16x3_pre_lw_kernel(PwArgs p) 
         issue(0, 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+#ifdef ASR_GEMM_PHASE_PROFILE
+        long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        long long tprev = (long long)__builtin_readcyclecounter();
+#endif
         for (int kt = 0; kt < KT; ++kt) {
             if (kt + 1 < KT) issue(kt + 1, (kt + 1) & 1);      // the other stage: last read before the previous barrier
+            PHASE_MARK(0);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // landed before anyone is released to read it
+            PHASE_MARK(1);
             __builtin_amdgcn_s_barrier();
+            PHASE_MARK(2);
         }
+#ifdef ASR_GEMM_PHASE_PROFILE
+        if (tid == 512 && orig < ASR_PHASE_BLOCKS)
+            for (int i = 0; i < 3; ++i) g_phase_cycles[orig * 16 + 8 + i] = ph[i];
+#endif
         return;
     }
 
@@ -849,21 +890,26 @@ __global__ __launch_bounds__(768, 3) void pw_gemm_f16x3_pre_lw_kernel(PwArgs p) 
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
 
+#ifdef ASR_GEMM_PHASE_PROFILE
+    long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long tprev = (long long)__builtin_readcyclecounter();
+#endif
     __builtin_amdgcn_s_barrier();                              // stage 0 landed (the loaders waited for it)
+    PHASE_MARK(0);
+#ifdef ASR_GEMM_PHASE_PROFILE
+    const long long loop_c0 = (long long)__builtin_readcyclecounter(), loop_r0 = (long long)__builtin_amdgcn_s_memrealtime();
+#endif
     for (int kt = 0; kt < KT; ++kt) {
         const char* const st = lds + (kt & 1) * STAGE_BYTES;
         // 2 halves x 8 column tiles = 16 groups of 6 MFMAs; the fragments of group g + 1 are requested before the MFMAs of
         // group g (one B double buffer, the A pair of the second half is requested under the last group of the first),
         // and a scheduling barrier per group keeps the compiler from hoisting every read to the top (it would need 160
         // fragment registers and spill).
-        f16x8 ah[2][2], al[2][2], bh[2], bl[2];
-        auto read_a = [&](int half, int buf) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int row = (wm * RT + 2 * half + i) * 16 + l16, swz = (row >> 1) & 7;
-                ah[buf][i] = *reinterpret_cast<const f16x8*>(st + row * 128 + ((oct ^ swz) << 4));
-                al[buf][i] = *reinterpret_cast<const f16x8*>(st + row * 128 + (((4 + oct) ^ swz) << 4));
-            }
+        f16x8 ah[2], al[2], bh[2], bl[2];
+        auto read_a = [&](int half, int i) {                   // hi / lo fragments of row tile 2 * half + i
+            const int row = (wm * RT + 2 * half + i) * 16 + l16, swz = (row >> 1) & 7;
+            ah[i] = *reinterpret_cast<const f16x8*>(st + row * 128 + ((oct ^ swz) << 4));
+            al[i] = *reinterpret_cast<const f16x8*>(st + row * 128 + (((4 + oct) ^ swz) << 4));
         };
         auto read_b = [&](int j, int buf) {
             const int col = (wn * CT + j) * 16 + l16;
@@ -871,25 +917,47 @@ __global__ __launch_bounds__(768, 3) void pw_gemm_f16x3_pre_lw_kernel(PwArgs p) 
             bl[buf] = *reinterpret_cast<const f16x8*>(st + A_BYTES + B_BYTES + (oct * BN + col) * 16);
         };
         read_a(0, 0);
+        read_a(0, 1);
         read_b(0, 0);
-#pragma unroll
-        for (int g = 0; g < 2 * CT; ++g) {
-            const int half = g / CT, j = g % CT;
+        auto group = [&](auto G) {
+            constexpr int g = decltype(G)::value, half = g / CT, j = g % CT;
+            constexpr bool last_of_half0 = g == CT - 1;
             if (g + 1 < 2 * CT) read_b((g + 1) % CT, (g + 1) & 1);
-            if (g == CT - 1) read_a(1, 1);
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 f32x4& a4 = acc[2 * half + i][j];
-                a4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[half][i], bh[g & 1], a4, 0, 0, 0);
-                a4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[half][i], bl[g & 1], a4, 0, 0, 0);
-                a4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[half][i], bh[g & 1], a4, 0, 0, 0);
+                a4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh[g & 1], a4, 0, 0, 0);
+                a4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl[g & 1], a4, 0, 0, 0);
+                a4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bh[g & 1], a4, 0, 0, 0);
+                if (last_of_half0) read_a(1, i);               // the second half's row tile into the registers just consumed
             }
+            // order inside the group: the next group's fragment reads first, then the MFMAs (the A refills behind their rows)
+            if (g + 1 < 2 * CT) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+            if (last_of_half0) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+            if (last_of_half0) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
             __builtin_amdgcn_sched_barrier(0);
-        }
+        };
+        asr_static_for<2 * CT>(group);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // this wave's reads of the stage are done
+        PHASE_MARK(2);
         __builtin_amdgcn_s_barrier();
+        PHASE_MARK(6);
     }
+#ifdef ASR_GEMM_PHASE_PROFILE
+    if (tid == 0 && orig < ASR_PHASE_BLOCKS) {
+        g_phase_cycles[orig * 16 + 11] = (long long)__builtin_readcyclecounter() - loop_c0;
+        g_phase_cycles[orig * 16 + 12] = (long long)__builtin_amdgcn_s_memrealtime() - loop_r0;
+    }
+#endif
     if (!(p.debug & 1)) pw_epilogue16<4, WN, RT, CT, true>(p, acc, smem, tile_m, tile_n, wave, lane);
+#ifdef ASR_GEMM_PHASE_PROFILE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    PHASE_MARK(7);
+    if (tid == 0 && orig < ASR_PHASE_BLOCKS)
+        for (int i = 0; i < 8; ++i) g_phase_cycles[orig * 16 + i] = ph[i];
+#endif
 }
 
 // =================================================================================================
@@ -1193,18 +1261,19 @@ static int launch_f16x3(PwArgs a, int forced_shape, asr_stream_t stream) {
     ASR_LAUNCH_CHECK();
 #ifdef ASR_GEMM_PHASE_PROFILE
     {
-        static long long host[ASR_PHASE_BLOCKS * 8];
+        static long long host[ASR_PHASE_BLOCKS * 16];
         ASR_HIP_CHECK(hipDeviceSynchronize());
         ASR_HIP_CHECK(hipMemcpyFromSymbol(host, HIP_SYMBOL(g_phase_cycles), sizeof(host)));
         const long long nb = nwg < ASR_PHASE_BLOCKS ? nwg : ASR_PHASE_BLOCKS;
-        double mean[8] = {0};
+        double mean[16] = {0};
         for (long long b = 0; b < nb; ++b)
-            for (int i = 0; i < 8; ++i) mean[i] += (double)host[b * 8 + i] / (double)nb;
+            for (int i = 0; i < 16; ++i) mean[i] += (double)host[b * 16 + i] / (double)nb;
         const int kt = (a.K + 31) / 32;
+        const int ktm = kt > 1 ? kt - 1 : 1;                     // phases that run between K-steps (none when K <= 32)
         fprintf(stderr, "[phase] M=%lld K=%d N=%d blocks=%lld ksteps=%d | prologue %.0f | per k-step: issue %.0f  lds+mfma %.0f  vmwait %.0f  "
                         "barrier1 %.0f  split+store %.0f  barrier2 %.0f | epilogue %.0f | block total %.0f cycles\n",
-                (long long)a.M, a.K, a.N, nwg, kt, mean[0], mean[1] / kt, mean[2] / kt, mean[3] / (kt - 1), mean[4] / (kt - 1), mean[5] / (kt - 1),
-                mean[6] / (kt - 1), mean[7], mean[0] + mean[1] + mean[2] + mean[3] + mean[4] + mean[5] + mean[6] + mean[7]);
+                (long long)a.M, a.K, a.N, nwg, kt, mean[0], mean[1] / kt, mean[2] / kt, mean[3] / ktm, mean[4] / ktm, mean[5] / ktm,
+                mean[6] / ktm, mean[7], mean[0] + mean[1] + mean[2] + mean[3] + mean[4] + mean[5] + mean[6] + mean[7]);
     }
 #endif
     return ASR_OK;
@@ -1284,11 +1353,28 @@ extern "C" int asr_pwconv_mfma_f16x3_presplit(const void* x_split, const float* 
         }
         hipLaunchKernelGGL(pw_gemm_f16x3_pre_lw_kernel<16>, dim3((unsigned)nwg), dim3(768), lds, asr_stream(stream), a);
         ASR_LAUNCH_CHECK();
+#ifdef ASR_GEMM_PHASE_PROFILE
+        {
+            static long long host[ASR_PHASE_BLOCKS * 16];
+            ASR_HIP_CHECK(hipDeviceSynchronize());
+            ASR_HIP_CHECK(hipMemcpyFromSymbol(host, HIP_SYMBOL(g_phase_cycles), sizeof(host)));
+            const long long nb = nwg < ASR_PHASE_BLOCKS ? nwg : ASR_PHASE_BLOCKS;
+            double mean[16] = {0};
+            for (long long b = 0; b < nb; ++b)
+                for (int i = 0; i < 16; ++i) mean[i] += (double)host[b * 16 + i] / (double)nb;
+            const int kt = a.Kpad / 32;
+            fprintf(stderr, "[phase-lw] M=%lld K=%d N=%d blocks=%lld ksteps=%d | mfma wave 0: prologue %.0f | per k-step: reads+mfma %.0f  barrier %.0f | "
+                            "epilogue %.0f || loader wave 8 per k-step: issue %.0f  landing wait %.0f  barrier %.0f || K loop %.0f cycles = %.2f us -> "
+                            "%.3f GHz, per k-step %.0f\n", (long long)a.M, a.K, a.N, nwg, kt, mean[0], mean[2] / kt, mean[6] / kt, mean[7], mean[8] / kt,
+                    mean[9] / kt, mean[10] / kt, mean[11], mean[12] / 100.0, mean[12] > 0 ? mean[11] / (mean[12] * 10.0) : 0.0, mean[11] / kt);
+        }
+#endif
         return ASR_OK;
     }
     // ASR_PRE_MFMA=32: the v_mfma_f32_32x32x16_f16 form (bit-identical to the in-kernel-split kernel) instead of 16x16x32
     static const bool m32 = getenv("ASR_PRE_MFMA") && atoi(getenv("ASR_PRE_MFMA")) == 32;
-    auto kern = m32 ? pw_gemm_f16x3_pre_kernel<4, 2, 2, 4, false> : pw_gemm_f16x3_pre_kernel<4, 2, 2, 4, true>;
+    static const bool hl = getenv("ASR_PRE_LW") && atoi(getenv("ASR_PRE_LW")) == 2;
+    auto kern = m32 ? pw_gemm_f16x3_pre_kernel<4, 2, 2, 4, false> : (hl ? pw_gemm_f16x3_pre_kernel<4, 2, 2, 4, true, true> : pw_gemm_f16x3_pre_kernel<4, 2, 2, 4, true>);
     static bool attr_set = false;
     if (!attr_set) {
         ASR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1298,18 +1384,20 @@ extern "C" int asr_pwconv_mfma_f16x3_presplit(const void* x_split, const float* 
     ASR_LAUNCH_CHECK();
 #ifdef ASR_GEMM_PHASE_PROFILE
     {
-        static long long host[ASR_PHASE_BLOCKS * 8];
+        static long long host[ASR_PHASE_BLOCKS * 16];
         ASR_HIP_CHECK(hipDeviceSynchronize());
         ASR_HIP_CHECK(hipMemcpyFromSymbol(host, HIP_SYMBOL(g_phase_cycles), sizeof(host)));
         const long long nb = nwg < ASR_PHASE_BLOCKS ? nwg : ASR_PHASE_BLOCKS;
-        double mean[8] = {0};
+        double mean[16] = {0};
         for (long long b = 0; b < nb; ++b)
-            for (int i = 0; i < 8; ++i) mean[i] += (double)host[b * 8 + i] / (double)nb;
+            for (int i = 0; i < 16; ++i) mean[i] += (double)host[b * 16 + i] / (double)nb;
         const int kt = a.Kpad / 32;
         fprintf(stderr, "[phase-pre] M=%lld K=%d N=%d blocks=%lld ksteps=%d | prologue %.0f | per k-step: issue %.0f  lds+mfma %.0f  "
                         "vmwait %.0f  barrier %.0f | epilogue (stores drained) %.0f | block total %.0f cycles\n",
                 (long long)a.M, a.K, a.N, nwg, kt, mean[0], mean[1] / kt, mean[2] / kt, mean[3] / kt, mean[6] / kt, mean[7],
                 mean[0] + mean[1] + mean[2] + mean[3] + mean[6] + mean[7]);
+        fprintf(stderr, "[phase-pre clock] K loop %.0f cycles = %.2f us -> %.3f GHz in-kernel | per k-step %.0f\n", mean[11], mean[12] / 100.0,
+                mean[12] > 0 ? mean[11] / (mean[12] * 10.0) : 0.0, mean[11] / kt);
     }
 #endif
     return ASR_OK;

@@ -1,9 +1,12 @@
 #!/bin/bash
-# Phase profile of the pre-split LDS-DMA GEMM only (diagnostic build, see tools/gemm_phase_profile.sh).
+# Phase profile of the pre-split LDS-DMA GEMMs (run on the GPU box).  The diagnostic library (s_memtime stamps per phase
+# of the K loop, a device synchronisation per launch) is built NEXT TO the product library, never in its place:
+# csrc/build.py with ASR_BUILD_VARIANT=phase -> libasr_hip_phase.so, selected for this run only through ASR_LIB.
 set -e
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p gpurun_out
-ASR_EXTRA_HIPFLAGS=-DASR_GEMM_PHASE_PROFILE python deeplabv3plus-augmented-superresolution_amd/csrc/build.py --force > gpurun_out/gemm_phase_build.log 2>&1
-python tools/bench_presplit.py > gpurun_out/gemm_phase_pre.log 2>&1
-grep "\[phase-pre" gpurun_out/gemm_phase_pre.log | tac | awk '!seen[$1 $2 $3 $4]++' | tac | cut -c1-330
-grep "^M=" gpurun_out/gemm_phase_pre.log | sed "s/in-kernel split 128x128 .* TF\/s  pre/pre/"
+lib=$(ASR_BUILD_VARIANT=phase python deeplabv3plus-augmented-superresolution_amd/csrc/build.py 2> gpurun_out/gemm_phase_build.log | tail -1)
+for lw in ${ASR_PHASE_VARIANTS:-0 1 2}; do
+  ASR_LIB=$lib ASR_PRE_LW=$lw python tools/bench_presplit.py > gpurun_out/gemm_phase_pre_lw$lw.log 2>&1
+  grep "\[phase-" gpurun_out/gemm_phase_pre_lw$lw.log | tac | awk '!seen[$1 $2 $3 $4 $5]++' | tac | cut -c1-420
+done
