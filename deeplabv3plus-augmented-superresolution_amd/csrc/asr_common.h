@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
+#include <atomic>
 #include "../../include/asr_hip.h"
 
 // ---- error plumbing -------------------------------------------------------------------
@@ -36,6 +37,28 @@ void asr_set_error(const char* fmt, ...);
     } while (0)
 
 #define ASR_LAUNCH_CHECK() ASR_HIP_CHECK(hipGetLastError())
+
+// ---- per-device once-initialisation ----------------------------------------------------
+// The library keeps no unsynchronised global state: a process may drive several devices from several host threads.  What is
+// cached (a kernel's dynamic-LDS allowance, a device's CU count) is cached PER DEVICE in atomics; the cached calls are
+// idempotent, so a race only repeats one.
+struct AsrDeviceOnce {
+    std::atomic<unsigned long long> mask{0};                   // bit d: done on device d (devices >= 64 are never cached)
+};
+
+static inline hipError_t asr_allow_dynamic_lds(AsrDeviceOnce& once, const void* kernel, int bytes) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const unsigned long long bit = (dev >= 0 && dev < 64) ? (1ull << dev) : 0ull;
+    if (bit && (once.mask.load(std::memory_order_acquire) & bit)) return hipSuccess;
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess && bit) once.mask.fetch_or(bit, std::memory_order_release);
+    return e;
+}
+
+// multiProcessorCount of the CURRENT device (core.cpp; cached per device), <= 0 on error
+int asr_device_cu_count();
 
 static inline hipStream_t asr_stream(asr_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 

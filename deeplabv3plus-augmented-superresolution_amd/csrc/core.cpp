@@ -16,3 +16,19 @@ extern "C" const char* asr_last_error(void) { return g_asr_error; }
 extern "C" int asr_abi_version(void) { return ASR_ABI_VERSION; }
 
 extern "C" const char* asr_target_arch(void) { return "gfx950"; }
+
+// multiProcessorCount of the current device, cached per device (atomics: several host threads / devices may call)
+int asr_device_cu_count() {
+    static std::atomic<int> cached[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return -1;
+    if (dev >= 0 && dev < 64) {
+        const int c = cached[dev].load(std::memory_order_acquire);
+        if (c > 0) return c;
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return -1;
+    const int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (dev >= 0 && dev < 64) cached[dev].store(cus, std::memory_order_release);
+    return cus;
+}

@@ -7,19 +7,17 @@
 //
 // HBM-bound (2.1 flop/byte).  Channels are the fastest axis, so a lane owns 4 consecutive
 // channels (one 16-byte access) and neighbouring lanes neighbouring channels: every global
-// access of a wave covers whole 256-byte pieces of pixel rows.  Four kernels:
+// access of a wave covers whole 256-byte pieces of pixel rows.  Kernels (an LDS-staged tile kernel was
+// measured at 3.5-4.0 TB/s against 3.8-5.6 TB/s for the streaming forms and is not built):
 //  * dw_stream_kernel<R,S,ROWS> (default for rate <= 2, stride 1 or 2 -- 93 % of the depthwise
 //    bytes): register sliding window.  A thread owns (4 channels, one output column) and marches
 //    down a strip of output rows keeping the (2R+1) x 3 taps in registers; the next input rows are
 //    loaded before the current row's FMAs; no barrier, >= 4 waves per SIMD.
-//  * dw_tiled_kernel<R>: LDS-staged (8+2R)x(16+2R)x64-channel input tile per workgroup (measured
-//    3.5-4.0 TB/s against 3.8-4.9 TB/s for the streaming form; kept selectable, ASR_DW_VARIANT=2).
 //  * aspp_dw3_kernel: the three dilated ASPP depthwise convs fused -- a whole H x W x 32-channel
 //    plane (128 KB at 32x32) is staged in LDS once and all three rates are computed from it, so
 //    the input is read from HBM once instead of three times.
 //  * dw_direct_kernel: any stride / rate, taps straight from L1/L2 (fallback).
 #include "asr_common.h"
-#include <stdlib.h>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -45,63 +43,6 @@ __device__ __forceinline__ f32x4 post_act4(f32x4 v, int mode) {
     if (mode) v = relu4(v);
     if (mode == 2) { v.x = fminf(v.x, 6.f); v.y = fminf(v.y, 6.f); v.z = fminf(v.z, 6.f); v.w = fminf(v.w, 6.f); }
     return v;
-}
-
-// ---------------------------------------------------------------------------------------------
-// LDS-tiled, stride 1
-// ---------------------------------------------------------------------------------------------
-constexpr int TH = 8, TW = 16, CB = 64;
-
-template <int R>
-__global__ __launch_bounds__(256) void dw_tiled_kernel(DwArgs p, int tiles_x) {
-    constexpr int ROWS = TH + 2 * R, COLS = TW + 2 * R;
-    __shared__ __attribute__((aligned(16))) float tile[ROWS * COLS * CB];
-    const int tid = threadIdx.x;
-    const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
-    const int cb = blockIdx.y * CB;
-    const int b = blockIdx.z;
-    const int oy0 = ty * TH, ox0 = tx * TW;
-    const int iy0 = oy0 - p.pad_top, ix0 = ox0 - p.pad_left;
-    const float* xin = p.x + (long long)b * p.h_in * p.w_in * p.ldx;
-
-    // stage the input tile (zero padded, pre-ReLU applied once)
-    for (int idx = tid; idx < ROWS * COLS * (CB / 4); idx += 256) {
-        const int c4 = idx & 15, pix = idx >> 4;
-        const int pr = pix / COLS, pc = pix - pr * COLS;
-        const int iy = iy0 + pr, ix = ix0 + pc, ch = cb + c4 * 4;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (iy >= 0 && iy < p.h_in && ix >= 0 && ix < p.w_in && ch < p.c) {
-            v = *reinterpret_cast<const f32x4*>(xin + ((long long)iy * p.w_in + ix) * p.ldx + ch);
-            if (p.pre_relu) v = relu4(v);
-        }
-        *reinterpret_cast<f32x4*>(tile + idx * 4) = v;
-    }
-    __syncthreads();
-
-    const int c4 = tid & 15, col = tid >> 4;
-    const int ch = cb + c4 * 4;
-    const int ox = ox0 + col;
-    if (ch >= p.c || ox >= p.w_out) return;
-    f32x4 wk[9];
-#pragma unroll
-    for (int t = 0; t < 9; ++t) wk[t] = *reinterpret_cast<const f32x4*>(p.w + (long long)t * p.c + ch);
-    const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + ch);
-    float* yout = p.y + (long long)b * p.h_out * p.w_out * p.ldy;
-#pragma unroll
-    for (int r = 0; r < TH; ++r) {
-        const int oy = oy0 + r;
-        if (oy >= p.h_out) break;
-        f32x4 acc = bv;
-#pragma unroll
-        for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                const f32x4 v = *reinterpret_cast<const f32x4*>(tile + (((r + ky * R) * COLS + col + kx * R) * (CB / 4) + c4) * 4);
-                acc += v * wk[ky * 3 + kx];
-            }
-        acc = post_act4(acc, p.post_relu);
-        *reinterpret_cast<f32x4*>(yout + ((long long)oy * p.w_out + ox) * p.ldy + ch) = acc;
-    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -321,77 +262,6 @@ __global__ __launch_bounds__(256) void dw_stream_full_kernel(DwArgs p, int tiles
     }
 }
 
-// Stride-1 variant of the register window with a FLAT (pixel, channel-quad) lane mapping: thread t of
-// a workgroup owns the 16-byte piece (row, f0 + t) of the image row seen as one contiguous array of
-// W * ld / 4 pieces, so every wave access is 1 KB contiguous (pixel boundaries included) and the
-// left / right taps are the same piece shifted by -+R pixels = -+R * ld floats.  No partially
-// filled channel chunk (728 = 11.4 x 64), whole-DRAM-burst accesses.  Needs ldx == ldy.
-template <int R, int SROWS>
-__global__ __launch_bounds__(256) void dw_flat_kernel(DwArgs p, int pieces_per_row) {
-    constexpr int WIN = 2 * R + 1;
-    const int q = p.ldx >> 2;                                  // 16-byte pieces per pixel
-    const int piece = blockIdx.x * 256 + threadIdx.x;          // along the image row
-    const int oy0 = blockIdx.y * SROWS;
-    const int b = blockIdx.z;
-    if (piece >= pieces_per_row) return;
-    const int ox = piece / q, c4 = piece - ox * q;
-    const int ch = c4 * 4;
-    if (ch >= p.c) return;                                     // stride padding lanes
-    const float* xin = p.x + (long long)b * p.h_in * p.w_in * p.ldx + (long long)piece * 4;
-    float* yout = p.y + (long long)b * p.h_out * p.w_out * p.ldy + (long long)piece * 4;
-    f32x4 wk[9];
-#pragma unroll
-    for (int t = 0; t < 9; ++t) wk[t] = *reinterpret_cast<const f32x4*>(p.w + (long long)t * p.c + ch);
-    const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + ch);
-    const int ixl = ox - p.pad_left, ixc = ixl + R, ixr = ixl + 2 * R;
-    const bool vl = ixl >= 0 && ixl < p.w_in, vc = ixc >= 0 && ixc < p.w_in, vr = ixr >= 0 && ixr < p.w_in;
-    const long long offl = (long long)(ixl - ox) * p.ldx, offc = (long long)(ixc - ox) * p.ldx, offr = (long long)(ixr - ox) * p.ldx;
-    const long long row_stride = (long long)p.w_in * p.ldx;
-    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-
-    auto load_row = [&](int iy, f32x4& l, f32x4& c, f32x4& r) {
-        l = zero; c = zero; r = zero;
-        if (iy >= 0 && iy < p.h_in) {
-            const float* row = xin + iy * row_stride;
-            if (vl) l = *reinterpret_cast<const f32x4*>(row + offl);
-            if (vc) c = *reinterpret_cast<const f32x4*>(row + offc);
-            if (vr) r = *reinterpret_cast<const f32x4*>(row + offr);
-            if (p.pre_relu) { l = relu4(l); c = relu4(c); r = relu4(r); }
-        }
-    };
-
-    f32x4 win[WIN][3], nl, nc, nr;
-    const int base0 = oy0 - p.pad_top;
-#pragma unroll
-    for (int k = 0; k < WIN - 1; ++k) load_row(base0 + k, win[k + 1][0], win[k + 1][1], win[k + 1][2]);
-    load_row(base0 + WIN - 1, nl, nc, nr);
-    const int rows = min(SROWS, p.h_out - oy0);
-    const long long out_stride = (long long)p.w_out * p.ldy;
-    for (int r = 0; r < rows; ++r) {
-#pragma unroll
-        for (int k = 0; k < WIN - 1; ++k) { win[k][0] = win[k + 1][0]; win[k][1] = win[k + 1][1]; win[k][2] = win[k + 1][2]; }
-        win[WIN - 1][0] = nl; win[WIN - 1][1] = nc; win[WIN - 1][2] = nr;
-        if (r + 1 < rows) load_row(base0 + WIN + r, nl, nc, nr);
-        f32x4 acc = bv;
-#pragma unroll
-        for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-            for (int kx = 0; kx < 3; ++kx) acc += win[ky * R][kx] * wk[ky * 3 + kx];
-        acc = post_act4(acc, p.post_relu);
-        *reinterpret_cast<f32x4*>(yout + (oy0 + r) * out_stride) = acc;
-    }
-}
-
-template <int R>
-void launch_flat(const DwArgs& p, hipStream_t s) {
-    static const int srows_env = getenv("ASR_DW_SROWS") ? atoi(getenv("ASR_DW_SROWS")) : 0;
-    const int pieces = p.w_out * (p.ldx >> 2);
-    const int srows = srows_env ? srows_env : (p.h_out <= 32 ? 16 : 32);
-    const dim3 grid((unsigned)asr_cdiv(pieces, 256), (unsigned)asr_cdiv(p.h_out, srows), p.batch);
-    if (srows == 8) hipLaunchKernelGGL((dw_flat_kernel<R, 8>), grid, dim3(256), 0, s, p, pieces);
-    else if (srows == 16) hipLaunchKernelGGL((dw_flat_kernel<R, 16>), grid, dim3(256), 0, s, p, pieces);
-    else hipLaunchKernelGGL((dw_flat_kernel<R, 32>), grid, dim3(256), 0, s, p, pieces);
-}
 
 // ---------------------------------------------------------------------------------------------
 // fused ASPP: three dilation rates from one LDS-resident plane
@@ -532,15 +402,13 @@ __global__ __launch_bounds__(256) void dw_direct_kernel(DwArgs p) {
 
 template <int R, int S>
 int launch_stream(const DwArgs& p, hipStream_t s, bool split = false) {
-    static const int srows_env = getenv("ASR_DW_SROWS") ? atoi(getenv("ASR_DW_SROWS")) : 0;
-    static const int generic_env = getenv("ASR_DW_GENERIC") ? atoi(getenv("ASR_DW_GENERIC")) : 0;
     const int tiles_x = (int)asr_cdiv(p.w_out, SCOLS), chunks = (int)asr_cdiv(p.c, 64);
-    const int srows = srows_env ? srows_env : (p.h_out <= 32 ? 16 : 32);
+    const int srows = p.h_out <= 32 ? 16 : 32;
     const dim3 grid(tiles_x * chunks, (unsigned)asr_cdiv(p.h_out, srows), p.batch);
     // full strips (every layer of the net): the branch-free kernel; 4 rows in flight on the small OS16 maps (few waves
     // per image), 1 on the large ones (measured); the two activation patterns of the Xception sepconvs are
-    // compiled in for the 16-row strips (the middle flow).  ASR_DW_GENERIC=1 selects the generic kernel (A/B runs).
-    if (!generic_env && p.h_out % srows == 0 && (srows == 16 || srows == 32)) {
+    // compiled in for the 16-row strips (the middle flow).  Ragged strips take the generic kernel below.
+    if (p.h_out % srows == 0) {
         const int act = (srows == 16) ? ((p.pre_relu == 1 && p.post_relu == 0) ? 1 : ((p.pre_relu == 0 && p.post_relu == 1) ? 2 : 0)) : 0;
 #define ASR_DW_FULL(SR_, PF_, ACT_)                                                                                              \
     do {                                                                                                                         \
@@ -555,15 +423,14 @@ int launch_stream(const DwArgs& p, hipStream_t s, bool split = false) {
         return ASR_OK;
     }
     ASR_UNSUPPORTED(split, "asr_dwconv3x3_nhwc_split_f16: needs h_out to be a multiple of the strip height (%d)", srows);
-    if (srows == 8) hipLaunchKernelGGL((dw_stream_kernel<R, S, 8>), grid, dim3(256), 0, s, p, tiles_x);
-    else if (srows == 16) hipLaunchKernelGGL((dw_stream_kernel<R, S, 16>), grid, dim3(256), 0, s, p, tiles_x);
+    if (srows == 16) hipLaunchKernelGGL((dw_stream_kernel<R, S, 16>), grid, dim3(256), 0, s, p, tiles_x);
     else hipLaunchKernelGGL((dw_stream_kernel<R, S, 32>), grid, dim3(256), 0, s, p, tiles_x);
     return ASR_OK;
 }
 
 }  // namespace
 
-// mode: 0 = auto, 1 = direct, 2 = streaming (register window), 3 = LDS-tiled, 4 = flat streaming
+// mode: 0 = auto, 1 = direct, 2 = streaming (register window)
 extern "C" int asr_dwconv3x3_nhwc_f32(const float* x, const float* w, const float* bias, float* y, int batch, int h_in,
                                       int w_in, int c, int stride, int rate, int pad_top, int pad_left, int h_out,
                                       int w_out, int ldx, int ldy, int pre_relu, int post_relu, int mode,
@@ -579,31 +446,18 @@ extern "C" int asr_dwconv3x3_nhwc_f32(const float* x, const float* w, const floa
     ASR_UNSUPPORTED((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(w) |
                      reinterpret_cast<uintptr_t>(bias)) & 15,
                     "asr_dwconv3x3_nhwc_f32: pointers must be 16-byte aligned");
-    ASR_REQUIRE(mode >= 0 && mode <= 4, "asr_dwconv3x3_nhwc_f32: mode must be 0..4");
+    ASR_REQUIRE(mode >= 0 && mode <= 2, "asr_dwconv3x3_nhwc_f32: mode must be 0 (auto), 1 (direct) or 2 (streaming)");
     DwArgs p{x, w, bias, y, batch, h_in, w_in, c, h_out, w_out, stride, rate, pad_top, pad_left, pre_relu, post_relu, ldx, ldy};
     hipStream_t s = asr_stream(stream);
-    static const int variant = getenv("ASR_DW_VARIANT") ? atoi(getenv("ASR_DW_VARIANT")) : 0;
-    const bool grid_ok = batch <= 65535;
-    const bool can_stream = grid_ok && ((stride == 1 && (rate == 1 || rate == 2)) || (stride == 2 && rate == 1));
-    const bool can_tile = grid_ok && stride == 1 && (rate == 1 || rate == 2);
-    const bool can_flat = can_tile && ldx == ldy && h_in == h_out && w_in == w_out;
-    // measured (profiles/): chunked streaming >= flat >= LDS-tiled on every layer of the net
-    if (mode == 0) mode = (variant == 2 && can_tile) ? 3 : ((variant == 4 && can_flat) ? 4 : (can_stream ? 2 : 1));
-    if (mode == 4) {
-        ASR_UNSUPPORTED(!can_flat, "asr_dwconv3x3_nhwc_f32: flat streaming kernel needs stride 1, rate 1|2, ldx == ldy, same-size output");
-        if (rate == 1) launch_flat<1>(p, s);
-        else launch_flat<2>(p, s);
-    } else if (mode == 2) {
+    const bool can_stream = batch <= 65535 && ((stride == 1 && (rate == 1 || rate == 2)) || (stride == 2 && rate == 1));
+    // (an LDS-tiled kernel and a flat lane mapping were measured at or below the streaming form on every layer of the net,
+    // DESIGN.md 4.2, and are not built)
+    if (mode == 0) mode = can_stream ? 2 : 1;
+    if (mode == 2) {
         ASR_UNSUPPORTED(!can_stream, "asr_dwconv3x3_nhwc_f32: streaming kernel needs (stride 1, rate 1|2) or (stride 2, rate 1)");
         if (stride == 1 && rate == 1) launch_stream<1, 1>(p, s);
         else if (stride == 1) launch_stream<2, 1>(p, s);
         else launch_stream<1, 2>(p, s);
-    } else if (mode == 3) {
-        ASR_UNSUPPORTED(!can_tile, "asr_dwconv3x3_nhwc_f32: tiled kernel needs stride 1 and rate 1 or 2");
-        const int tiles_x = (int)asr_cdiv(w_out, TW), tiles_y = (int)asr_cdiv(h_out, TH);
-        const dim3 grid(tiles_x * tiles_y, (unsigned)asr_cdiv(c, CB), batch);
-        if (rate == 1) hipLaunchKernelGGL(dw_tiled_kernel<1>, grid, dim3(256), 0, s, p, tiles_x);
-        else hipLaunchKernelGGL(dw_tiled_kernel<2>, grid, dim3(256), 0, s, p, tiles_x);
     } else {
         const long long total = (long long)batch * h_out * w_out * (c >> 2);
         const long long g = asr_cdiv(total, 256);
@@ -661,12 +515,9 @@ static int aspp_common(bool split, const float* x, const float* w3, const float*
     const size_t lds = sizeof(float) * (size_t)h * w * ACB;
     ASR_UNSUPPORTED(lds > 160 * 1024, "asr_aspp_dwconv3: %dx%d plane x %d channels (%zu B) exceeds the 160 KB LDS; "
                     "use asr_dwconv3x3_nhwc_f32 per branch", h, w, ACB, lds);
-    static bool attr_set = false;
-    if (!attr_set) {
-        ASR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(aspp_dw3_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        ASR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(aspp_dw3_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
+    static AsrDeviceOnce once_f32, once_split;
+    ASR_HIP_CHECK(asr_allow_dynamic_lds(once_f32, reinterpret_cast<const void*>(aspp_dw3_kernel<false>), 160 * 1024));
+    ASR_HIP_CHECK(asr_allow_dynamic_lds(once_split, reinterpret_cast<const void*>(aspp_dw3_kernel<true>), 160 * 1024));
     AsppArgs p{};
     p.x = x; p.w = w3; p.bias = bias3;
     p.y[0] = static_cast<float*>(y0); p.y[1] = static_cast<float*>(y1); p.y[2] = static_cast<float*>(y2);

@@ -20,8 +20,6 @@
 //    consecutive logical ids, and logical ids are dealt so that consecutive ones share an XCD
 //    (private L2), using the bijective remap.
 #include "asr_common.h"
-#include <stdlib.h>
-#include <utility>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -45,7 +43,6 @@ struct PwArgs {
     int taps;  // 1 = pointwise (optionally spatially subsampled), 9 = 3x3 implicit GEMM
     int cin;   // channels per tap
     int h_in, w_in, h_out, w_out, stride, pad, dil;
-    int debug;  // timing experiments only (ASR_GEMM_DEBUG): bit0 skip the epilogue, bit3 skip the MFMA section (pre-split kernel)
 };
 
 // ---- epilogue shared by the f32 and the split-f16 kernels ------------------------------------------
@@ -127,9 +124,7 @@ __device__ __forceinline__ void pw_epilogue(const PwArgs& p, f32x16 (&acc)[TM][T
 // pw_epilogue for accumulators of v_mfma_f32_16x16x32_f16: acc[rt][ct] (f32x4) holds rows rt * 16 + 4 * (lane >> 4) + r
 // (r = 0..3), column ct * 16 + (lane & 15) of the wave's (RT * 16) x (CT * 16) sub-tile.  Same LDS transposition, residual
 // prefetch and 16-byte stores as pw_epilogue<..., RES_AHEAD = true>; only the staging map differs.
-// RES_INLINE (kernels at 168 registers per wave): no residual prefetch -- each residual piece is loaded where it is added, so
-// the 64 registers of the prefetch queue are free for the accumulators of the slabs still waiting.
-template <int WM, int WN, int RT, int CT, bool RES_INLINE = false>
+template <int WM, int WN, int RT, int CT>
 __device__ __forceinline__ void pw_epilogue16(const PwArgs& p, f32x4 (&acc)[RT][CT], float* smem, int tile_m, int tile_n, int wave, int lane) {
     constexpr int BM = WM * RT * 16, BN = WN * CT * 16, WCOLS = CT * 16;
     constexpr int LPR = WCOLS / 4, RPI = 64 / LPR;
@@ -152,17 +147,14 @@ __device__ __forceinline__ void pw_epilogue16(const PwArgs& p, f32x4 (&acc)[RT][
     for (int i = 0; i < RT / 2; ++i) {                         // 32-row slabs
         const long long m_base = (long long)tile_m * BM + (wm * RT + 2 * i) * 16;
         f32x4 rv[32 / RPI];
-        auto request_residual = [&]() {
-            if (res_vec) {
-                const float* rbase = p.res + (n < p.N ? n : 0);
+        if (res_vec) {
+            const float* rbase = p.res + (n < p.N ? n : 0);
 #pragma unroll
-                for (int q = 0; q < 32 / RPI; ++q) {
-                    const long long m = m_base + q * RPI + r_in;
-                    rv[q] = *reinterpret_cast<const f32x4*>(rbase + (m < p.M ? m : p.M - 1) * p.ldres);
-                }
+            for (int q = 0; q < 32 / RPI; ++q) {
+                const long long m = m_base + q * RPI + r_in;
+                rv[q] = *reinterpret_cast<const f32x4*>(rbase + (m < p.M ? m : p.M - 1) * p.ldres);
             }
-        };
-        if (!RES_INLINE) request_residual();
+        }
 #pragma unroll
         for (int h2 = 0; h2 < 2; ++h2)
 #pragma unroll
@@ -181,7 +173,7 @@ __device__ __forceinline__ void pw_epilogue16(const PwArgs& p, f32x4 (&acc)[RT][
             f32x4 v = *reinterpret_cast<const f32x4*>(stage + r * WCOLS + c4 * 4);
             if (m < p.M && n < p.N) {
                 if (vec_ok) {
-                    if (p.res) v += RES_INLINE ? *reinterpret_cast<const f32x4*>(p.res + m * p.ldres + n) : rv[q];
+                    if (p.res) v += rv[q];
                     *reinterpret_cast<f32x4*>(p.y + m * p.ldy + n) = v;
                 } else {
 #pragma unroll
@@ -197,15 +189,16 @@ __device__ __forceinline__ void pw_epilogue16(const PwArgs& p, f32x4 (&acc)[RT][
     }
 }
 
-template <int WM, int WN, int TM, int TN, bool CONV, bool DBUF>
+template <int WM, int WN, int TM, int TN, bool CONV>
 __global__ __launch_bounds__(256) void pw_gemm_kernel(PwArgs p) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int A_F4 = BM / 32;  // float4 staged per thread per K-tile
     constexpr int B_F4 = BN / 32;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int NBUF = DBUF ? 2 : 1;
-    float* const sA = smem;                   // [NBUF][BM*32]
-    float* const sB = smem + NBUF * BM * BK;  // [NBUF][32*BN]
+    // ONE staging buffer (32 KB at 128 x 128): five workgroups = five waves per SIMD hide the two staging barriers better
+    // than a double-buffered form at two workgroups per CU (measured +9 % on the whole forward pass).
+    float* const sA = smem;                   // [BM*32]
+    float* const sB = smem + BM * BK;         // [32*BN]
 
     // XCD-aware bijective remap of the workgroup id (speed only)
     const int nwg = gridDim.x, orig = blockIdx.x;
@@ -276,9 +269,9 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwArgs p) {
             rb[i] = *reinterpret_cast<const f32x4*>(b_base + ((long long)(k0 / 4 + kq) * p.Npad + n) * 4);
         }
     };
-    auto store_tile = [&](int buf) {
-        float* dA = sA + buf * BM * BK;
-        float* dB = sB + buf * BK * BN;
+    auto store_tile = [&]() {
+        float* dA = sA;
+        float* dB = sB;
 #pragma unroll
         for (int i = 0; i < A_F4; ++i) {
             const int row = (tid >> 3) + 32 * i;
@@ -301,14 +294,13 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwArgs p) {
 
     const int KT = (p.K + BK - 1) / BK;
     load_tile(0);
-    store_tile(0);
+    store_tile();
     __syncthreads();
 
     for (int kt = 0; kt < KT; ++kt) {
-        const int buf = DBUF ? (kt & 1) : 0;
         if (kt + 1 < KT) load_tile(kt + 1);
-        const float* cA = sA + buf * BM * BK;
-        const float* cB = sB + buf * BK * BN;
+        const float* cA = sA;
+        const float* cB = sB;
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             const int slot = 2 * kk + hh;
@@ -331,29 +323,17 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwArgs p) {
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][t], b[j][t], acc[i][j], 0, 0, 0);
         }
-        if (DBUF) {
-            if (kt + 1 < KT) store_tile(buf ^ 1);
-            __syncthreads();
-        } else if (kt + 1 < KT) {
+        if (kt + 1 < KT) {
             __syncthreads();      // every wave has finished reading the tile
-            store_tile(0);
+            store_tile();
             __syncthreads();
         }
     }
 
     // ---- epilogue: bias, ReLU, residual, store ------------------------------------------------
     // C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-    if (p.debug & 1) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) asm volatile("" ::"v"(acc[i][j][e]));
-        return;
-    }
-    if (!DBUF) __syncthreads();                    // all waves are done reading the last K-tile
-    static_assert(WM * WN * 32 * TN * 32 <= NBUF * (BM * BK + BK * BN), "epilogue staging does not fit the LDS");
+    __syncthreads();                               // all waves are done reading the last K-tile
+    static_assert(WM * WN * 32 * TN * 32 <= BM * BK + BK * BN, "epilogue staging does not fit the LDS");
     pw_epilogue<WM, WN, TM, TN>(p, acc, smem, tile_m, tile_n, wave, lane);
 }
 
@@ -398,13 +378,12 @@ __device__ long long g_phase_cycles[ASR_PHASE_BLOCKS * 16];    // per block: 0-7
 #define PHASE_WAIT_LGKM()
 #endif
 
-template <int WM, int WN, int TM, int TN, bool DBUF, int MINW, bool CONV>
-__global__ __launch_bounds__(WM * WN * 64, MINW) void pw_gemm_f16x3_kernel(PwArgs p) {
+template <int WM, int WN, int TM, int TN, bool CONV>
+__global__ __launch_bounds__(WM * WN * 64) void pw_gemm_f16x3_kernel(PwArgs p) {
     constexpr int NT = WM * WN * 64, BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int PA = BM * 4 / NT;                    // (row, 32-byte k-slot) items of the A tile per thread
     constexpr int PB = BN * 4 / NT;                    // (k-octet, column) items of the B tile per thread and plane
     static_assert((BM * 4) % NT == 0 && (BN * 4) % NT == 0 && (BN & (BN - 1)) == 0, "tile / thread-count mismatch");
-    constexpr int STAGE = 2 * BK * (BM + BN);          // halfs per LDS stage (A_hi, A_lo, B_hi, B_lo)
     // dynamic LDS = max(stages, epilogue staging of WM*WN waves x 32 x TN*32 floats), sized by the launcher
     extern __shared__ __attribute__((aligned(16))) float smem[];
     _Float16* const sAh = reinterpret_cast<_Float16*>(smem);   // [BM rows][32]          (+ stage offset)
@@ -484,8 +463,8 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void pw_gemm_f16x3_kernel(PwArg
             rbl[i] = *reinterpret_cast<const f16x8*>(wh + plane + off);
         }
     };
-    auto store_tile = [&](int buf) {
-        const int so = buf * STAGE;
+    auto store_tile = [&]() {
+        constexpr int so = 0;
 #pragma unroll
         for (int i = 0; i < PA; ++i) {
             const int row = (tid >> 2) + (NT / 4) * i;
@@ -517,15 +496,15 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void pw_gemm_f16x3_kernel(PwArg
     long long tprev = (long long)__builtin_readcyclecounter();
 #endif
     load_tile(0);
-    store_tile(0);
+    store_tile();
     __syncthreads();
     PHASE_MARK(0);                                             // prologue: first tile in, LDS filled
     for (int kt = 0; kt < KT; ++kt) {
-        const int so = DBUF ? (kt & 1) * STAGE : 0;
+        constexpr int so = 0;
         // All loads of the next tile go out before the MFMAs: a wave stalls ~250 cycles in the vector-memory issue queue
         // per 1 KiB load while every wave of the CU is loading, and spreading the loads between MFMA groups (tried) only
         // spreads that stall over the matrix pipe's busy phase (-15 %).
-        if (kt + 1 < KT && !(p.debug & 2)) load_tile(kt + 1);
+        if (kt + 1 < KT) load_tile(kt + 1);
         PHASE_MARK(1);                                         // global loads issued
 #pragma unroll
         for (int s = 0; s < BK / 16; ++s) {
@@ -571,25 +550,15 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void pw_gemm_f16x3_kernel(PwArg
         }
         PHASE_MARK(2);                                         // LDS fragment reads + MFMA issue
         if (kt + 1 < KT) {
-            if (DBUF) {
-                PHASE_WAIT_VM();
-                PHASE_MARK(3);                                 // next tile's global loads landed
-                store_tile((kt + 1) & 1);
-                PHASE_WAIT_LGKM();
-                PHASE_MARK(5);                                 // split to f16 + LDS stores (other stage)
-                __syncthreads();
-                PHASE_MARK(6);
-            } else {
-                PHASE_WAIT_VM();
-                PHASE_MARK(3);                                 // next tile's global loads landed
-                __syncthreads();
-                PHASE_MARK(4);                                 // every wave done reading the tile
-                store_tile(0);
-                PHASE_WAIT_LGKM();
-                PHASE_MARK(5);                                 // split to f16 + LDS stores
-                __syncthreads();
-                PHASE_MARK(6);                                 // stores of every wave visible
-            }
+            PHASE_WAIT_VM();
+            PHASE_MARK(3);                                     // next tile's global loads landed
+            __syncthreads();
+            PHASE_MARK(4);                                     // every wave done reading the tile
+            store_tile();
+            PHASE_WAIT_LGKM();
+            PHASE_MARK(5);                                     // split to f16 + LDS stores
+            __syncthreads();
+            PHASE_MARK(6);                                     // stores of every wave visible
         }
     }
     __syncthreads();
@@ -619,10 +588,7 @@ __device__ __forceinline__ void glds16(const void* g, void* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((asr_gbl_ptr)g, (asr_lds_ptr)lds_wave_base, 16, 0, 0);
 }
 
-// HL ("half load"): only the second-dispatched half of the waves (4-7, the SIMD partners that lose the matrix-pipe
-// arbitration to waves 0-3 anyway) requests the next stage -- 16 pieces each, their own and their partner's -- while waves
-// 0-3 go straight to their MFMAs; waves 4-7 run their MFMAs when the pipe frees up.
-template <int WM, int WN, int TM, int TN, bool M16, bool HL = false>
+template <int WM, int WN, int TM, int TN>
 __global__ __launch_bounds__(WM * WN * 64, 2) void pw_gemm_f16x3_pre_kernel(PwArgs p) {
     constexpr int NT = WM * WN * 64, BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int A_BYTES = BM * 128, B_BYTES = 4 * BN * 16, STAGE_BYTES = A_BYTES + 2 * B_BYTES;
@@ -637,70 +603,47 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void pw_gemm_f16x3_pre_kernel(PwAr
     const int tile_m = lid / p.tiles_n, tile_n = lid % p.tiles_n;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
-    const int l32 = lane & 31, hh = lane >> 5;
 
-    // per-thread DMA sources: A piece q = slot_wave * 64 + lane + NT * i -> (row q >> 3, LDS slot q & 7, holding global
-    // slot ^ swizzle); a wave requests the pieces of NS wave slots (HL: its partner's and its own)
-    constexpr int NS = HL ? 2 : 1;
-    const bool requester = !HL || wave >= WM * WN / 2;
-    const char* a_src[NS][PA];
-    const char* b_src[NS][PB];
-    int slot_wave[NS];
+    // per-thread DMA sources: A piece q = tid + NT * i -> (row q >> 3, LDS slot q & 7, holding global slot ^ swizzle)
+    const char* a_src[PA];
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+        const int q = tid + NT * i, row = q >> 3, slot = (q & 7) ^ ((row >> 1) & 7);
+        long long m = (long long)tile_m * BM + row;
+        if (m >= p.M) m = p.M - 1;                             // rows past the end re-read the last row; never stored
+        a_src[i] = reinterpret_cast<const char*>(p.x) + (m * p.ldx) * 128 + slot * 16;   // + kt * 128 per K chunk
+    }
     const long long plane_bytes = (long long)p.Kpad * p.Npad * 2;
+    const char* b_src[PB];
 #pragma unroll
-    for (int sl = 0; sl < NS; ++sl) {
-        slot_wave[sl] = HL ? ((wave & (WM * WN / 2 - 1)) + sl * (WM * WN / 2)) : wave;
-#pragma unroll
-        for (int i = 0; i < PA; ++i) {
-            const int q = slot_wave[sl] * 64 + lane + NT * i, row = q >> 3, slot = (q & 7) ^ ((row >> 1) & 7);
-            long long m = (long long)tile_m * BM + row;
-            if (m >= p.M) m = p.M - 1;                         // rows past the end re-read the last row; never stored
-            a_src[sl][i] = reinterpret_cast<const char*>(p.x) + (m * p.ldx) * 128 + slot * 16;   // + kt * 128 per K chunk
-        }
-#pragma unroll
-        for (int i = 0; i < PB; ++i) {
-            const int q = slot_wave[sl] * 64 + lane + NT * i, oct = q / BN, col = q % BN;
-            b_src[sl][i] = reinterpret_cast<const char*>(p.wp) + (((long long)oct * p.Npad) + (long long)tile_n * BN + col) * 16;  // + kt * 4 * Npad * 16
-        }
+    for (int i = 0; i < PB; ++i) {
+        const int q = tid + NT * i, oct = q / BN, col = q % BN;
+        b_src[i] = reinterpret_cast<const char*>(p.wp) + (((long long)oct * p.Npad) + (long long)tile_n * BN + col) * 16;  // + kt * 4 * Npad * 16
     }
     const long long b_kstep = (long long)4 * p.Npad * 16;
 
     auto issue_tile = [&](int kt, int stage) {
-        if (!requester) return;
         char* const st = lds + stage * STAGE_BYTES;
 #pragma unroll
-        for (int sl = 0; sl < NS; ++sl) {
+        for (int i = 0; i < PA; ++i) glds16(a_src[i] + (long long)kt * 128, st + (wave * 64 + NT * i) * 16);
 #pragma unroll
-            for (int i = 0; i < PA; ++i) glds16(a_src[sl][i] + (long long)kt * 128, st + (slot_wave[sl] * 64 + NT * i) * 16);
-#pragma unroll
-            for (int i = 0; i < PB; ++i) {
-                glds16(b_src[sl][i] + kt * b_kstep, st + A_BYTES + (slot_wave[sl] * 64 + NT * i) * 16);
-                glds16(b_src[sl][i] + kt * b_kstep + plane_bytes, st + A_BYTES + B_BYTES + (slot_wave[sl] * 64 + NT * i) * 16);
-            }
+        for (int i = 0; i < PB; ++i) {
+            glds16(b_src[i] + kt * b_kstep, st + A_BYTES + (wave * 64 + NT * i) * 16);
+            glds16(b_src[i] + kt * b_kstep + plane_bytes, st + A_BYTES + B_BYTES + (wave * 64 + NT * i) * 16);
         }
     };
 
-    // M16: v_mfma_f32_16x16x32_f16 (one MFMA spans the whole 32-deep K-step) instead of v_mfma_f32_32x32x16_f16.  Same
-    // flops per cycle on paper, but under the chip's power management the 16x16x32 shape sustains ~1.18x the rate of the
-    // 32x32x16 one (tools/ubench_mfma_shapes.hip: 1.55-1.82 vs 1.86-2.20 PFLOP/s in bare loops), and this K loop runs AT
-    // the sustained MFMA rate (the clock gives back whatever a reordering of requests and MFMAs gains).
-    f32x16 acc[M16 ? 1 : TM][M16 ? 1 : TN];
-    f32x4 acc16[M16 ? 2 * TM : 1][M16 ? 2 * TN : 1];
-    if (M16) {
+    // v_mfma_f32_16x16x32_f16: one MFMA spans the whole 32-deep K-step.  Same flops per cycle on paper as the 32x32x16
+    // shape, but under the chip's power management it sustains ~1.18x the rate (profiles/r01_gemm_phase_profile.txt:
+    // 1.55-1.82 vs 1.86-2.20 PFLOP/s in bare loops) and has four independent accumulator chains per column tile.
+    constexpr int RT = 2 * TM, CT = 2 * TN;                    // 16 x 16 tiles of the wave's (RT * 16) x (CT * 16) sub-tile
+    f32x4 acc[RT][CT];
 #pragma unroll
-        for (int i = 0; i < 2 * TM; ++i)
+    for (int i = 0; i < RT; ++i)
 #pragma unroll
-            for (int j = 0; j < 2 * TN; ++j)
+        for (int j = 0; j < CT; ++j)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) acc16[M16 ? i : 0][M16 ? j : 0][e] = 0.f;
-    } else {
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc[M16 ? 0 : i][M16 ? 0 : j][e] = 0.f;
-    }
+            for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
 
     const int KT = p.Kpad / BK;
 #ifdef ASR_GEMM_PHASE_PROFILE
@@ -713,322 +656,14 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void pw_gemm_f16x3_pre_kernel(PwAr
 #ifdef ASR_GEMM_PHASE_PROFILE
     const long long loop_c0 = (long long)__builtin_readcyclecounter(), loop_r0 = (long long)__builtin_amdgcn_s_memrealtime();
 #endif
+    const int l16 = lane & 15, oct = lane >> 4;                // A: row = l16, k = 8 oct ..; B: column = l16, same k
     for (int kt = 0; kt < KT; ++kt) {
         const char* const st = lds + (kt & 1) * STAGE_BYTES;
-        // All 8 DMA pieces of the next tile go out before the MFMAs (spreading them between the MFMA groups, or letting
-        // half of the waves request theirs after their MFMAs, measured equal / 8 % slower).
+        // All 8 DMA pieces of the next tile go out before the MFMAs (spreading them between the MFMA groups, letting half of
+        // the waves request, or giving the requests to four dedicated loader waves all measured equal in wall clock:
+        // DESIGN.md 4.1, profiles/r02_gemm_loader_wave_experiment.txt).
         if (kt + 1 < KT) issue_tile(kt + 1, (kt + 1) & 1);     // the other stage: last read before the previous barrier
         PHASE_MARK(1);
-        if (M16) {
-            const int l16 = lane & 15, oct = lane >> 4;        // A: row = l16, k = 8 oct ..; B: column = l16, same k
-            f16x8 ah[2 * TM], al[2 * TM];
-#pragma unroll
-            for (int i = 0; i < 2 * TM; ++i) {
-                const int row = (wm * 2 * TM + i) * 16 + l16, swz = (row >> 1) & 7;
-                ah[i] = *reinterpret_cast<const f16x8*>(st + row * 128 + ((oct ^ swz) << 4));
-                al[i] = *reinterpret_cast<const f16x8*>(st + row * 128 + (((4 + oct) ^ swz) << 4));
-            }
-#pragma unroll
-            for (int j = 0; j < 2 * TN; ++j) {
-                const int col = (wn * 2 * TN + j) * 16 + l16;
-                const f16x8 bh = *reinterpret_cast<const f16x8*>(st + A_BYTES + (oct * BN + col) * 16);
-                const f16x8 bl = *reinterpret_cast<const f16x8*>(st + A_BYTES + B_BYTES + (oct * BN + col) * 16);
-#pragma unroll
-                for (int i = 0; i < 2 * TM; ++i) {
-                    f32x4& a4 = acc16[M16 ? i : 0][M16 ? j : 0];
-                    a4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh, a4, 0, 0, 0);
-                    a4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl, a4, 0, 0, 0);
-                    a4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bh, a4, 0, 0, 0);
-                }
-            }
-        } else
-        if (!(p.debug & 8))
-#pragma unroll
-        for (int s = 0; s < BK / 16; ++s) {
-            const int oct = 2 * s + hh;
-            f16x8 ah[TM], al[TM];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const int row = (wm * TM + i) * 32 + l32, swz = (row >> 1) & 7;
-                ah[i] = *reinterpret_cast<const f16x8*>(st + row * 128 + ((oct ^ swz) << 4));
-                al[i] = *reinterpret_cast<const f16x8*>(st + row * 128 + (((4 + oct) ^ swz) << 4));
-            }
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int col = (wn * TN + j) * 32 + l32;
-                const f16x8 bh = *reinterpret_cast<const f16x8*>(st + A_BYTES + (oct * BN + col) * 16);
-                const f16x8 bl = *reinterpret_cast<const f16x8*>(st + A_BYTES + B_BYTES + (oct * BN + col) * 16);
-#pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh, acc[i][j], 0, 0, 0);
-                }
-            }
-        }
-        PHASE_MARK(2);
-        PHASE_WAIT_VM();
-        PHASE_MARK(3);
-        __syncthreads();                                       // next stage landed (vmcnt(0)) and everyone is done reading this one
-        PHASE_MARK(6);
-    }
-#ifdef ASR_GEMM_PHASE_PROFILE
-    if (tid == 0 && orig < ASR_PHASE_BLOCKS) {
-        g_phase_cycles[orig * 16 + 11] = (long long)__builtin_readcyclecounter() - loop_c0;
-        g_phase_cycles[orig * 16 + 12] = (long long)__builtin_amdgcn_s_memrealtime() - loop_r0;
-    }
-#endif
-    if (M16) {
-        if (!(p.debug & 1)) pw_epilogue16<WM, WN, (M16 ? 2 * TM : 2), (M16 ? 2 * TN : 1)>(p, reinterpret_cast<f32x4(&)[M16 ? 2 * TM : 2][M16 ? 2 * TN : 1]>(acc16), smem, tile_m, tile_n, wave, lane);
-    } else {
-        if (!(p.debug & 1)) pw_epilogue<WM, WN, (M16 ? 1 : TM), (M16 ? 1 : TN), true>(p, acc, smem, tile_m, tile_n, wave, lane);
-        else if (acc[0][0][0] == 12345.678f) p.y[0] = acc[0][0][5];
-    }
-#ifdef ASR_GEMM_PHASE_PROFILE
-    PHASE_WAIT_VM();
-    PHASE_MARK(7);
-    if (tid == 0 && orig < ASR_PHASE_BLOCKS)
-        for (int i = 0; i < 8; ++i) g_phase_cycles[orig * 16 + i] = ph[i];
-#endif
-}
-
-// =================================================================================================
-// Loader-wave form of the pre-split kernel (same 256 x 256 tile, same two 64 KB LDS stages, same MFMA sequence per
-// accumulator => bit-identical results).  The phase profile of pw_gemm_f16x3_pre_kernel shows the matrix pipe idle for the
-// ~1000 cycles per K-step in which all eight waves sit in the vector-memory issue queue requesting the next stage (a wave
-// pays ~150 cycles per 1 KiB LDS-DMA piece whoever issues it, and a wave that is issuing cannot issue MFMAs).  Here
-// the twelve waves of the workgroup have fixed roles: waves 0-7 only read fragments and issue MFMAs (they never execute a
-// vector-memory instruction inside the K loop), waves 8-11 -- one per SIMD -- only request: 16 pieces each per K-step
-// (~2400 cycles of issue, under the 3100 cycles the two MFMA waves of the SIMD need), then wait for their landing and
-// meet the MFMA waves at the K-step's barrier.  Three waves per SIMD leave 168 registers per wave: the MFMA waves hold
-// the 128 accumulators and walk their 64 x 128 tile in two 32-row halves (A fragments of two row tiles at a time, the B
-// fragments are read once per half).
-// =================================================================================================
-template <typename F, int... I>
-__device__ __forceinline__ void asr_static_for_impl(F& f, std::integer_sequence<int, I...>) {
-    (f(std::integral_constant<int, I>{}), ...);
-}
-template <int N, typename F>
-__device__ __forceinline__ void asr_static_for(F& f) {
-    asr_static_for_impl(f, std::make_integer_sequence<int, N>{});
-}
-
-template <int PIECES_PER_LOADER = 16>
-__global__ __launch_bounds__(768, 3) void pw_gemm_f16x3_pre_lw_kernel(PwArgs p) {
-    constexpr int BM = 256, BN = 256, WN = 2, RT = 4, CT = 8;
-    constexpr int A_BYTES = BM * 128, B_BYTES = 4 * BN * 16, STAGE_BYTES = A_BYTES + 2 * B_BYTES;
-    constexpr int A_PIECES = A_BYTES / 1024;                   // 32 pieces of 64 lanes x 16 B; then 32 B pieces (hi plane, lo plane)
-    static_assert(4 * PIECES_PER_LOADER * 1024 == STAGE_BYTES, "four loader waves cover one stage");
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    char* const lds = reinterpret_cast<char*>(smem);
-
-    const int nwg = gridDim.x, orig = blockIdx.x;
-    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
-    const int lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
-    const int tile_m = lid / p.tiles_n, tile_n = lid % p.tiles_n;
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int KT = p.Kpad / BK;
-
-    if (wave >= 8) {
-        // ---- loader wave: pieces (wave - 8) * 16 .. + 15 of every stage ------------------------------------------
-        const int first = (wave - 8) * PIECES_PER_LOADER;
-        const char* src[PIECES_PER_LOADER];
-        long long kstep[2];                                     // byte advance per K-step: A pieces, B pieces
-        kstep[0] = 128;
-        kstep[1] = (long long)4 * p.Npad * 16;
-        const long long plane_bytes = (long long)p.Kpad * p.Npad * 2;
-#pragma unroll
-        for (int j = 0; j < PIECES_PER_LOADER; ++j) {
-            const int pi = first + j;
-            if (pi < A_PIECES) {                                // A: (row q >> 3, LDS slot q & 7 holding global slot ^ swizzle)
-                const int q = pi * 64 + lane, row = q >> 3, slot = (q & 7) ^ ((row >> 1) & 7);
-                long long m = (long long)tile_m * BM + row;
-                if (m >= p.M) m = p.M - 1;                      // rows past the end re-read the last row; never stored
-                src[j] = reinterpret_cast<const char*>(p.x) + (m * p.ldx) * 128 + slot * 16;
-            } else {                                            // B: plane (hi, lo), k-octet, column
-                const int qb = (pi - A_PIECES) * 64 + lane, plane = qb >> 10, r = qb & 1023, oct = r >> 8, col = r & 255;
-                src[j] = reinterpret_cast<const char*>(p.wp) + plane * plane_bytes +
-                         (((long long)oct * p.Npad) + (long long)tile_n * BN + col) * 16;
-            }
-        }
-        auto issue = [&](int kt, int stage) {
-            char* const st = lds + stage * STAGE_BYTES + first * 1024;
-#pragma unroll
-            for (int j = 0; j < PIECES_PER_LOADER; ++j)
-                glds16(src[j] + kt * kstep[(first + j) < A_PIECES ? 0 : 1], st + j * 1024);
-        };
-        issue(0, 0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-#ifdef ASR_GEMM_PHASE_PROFILE
-        long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        long long tprev = (long long)__builtin_readcyclecounter();
-#endif
-        for (int kt = 0; kt < KT; ++kt) {
-            if (kt + 1 < KT) issue(kt + 1, (kt + 1) & 1);      // the other stage: last read before the previous barrier
-            PHASE_MARK(0);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // landed before anyone is released to read it
-            PHASE_MARK(1);
-            __builtin_amdgcn_s_barrier();
-            PHASE_MARK(2);
-        }
-#ifdef ASR_GEMM_PHASE_PROFILE
-        if (tid == 512 && orig < ASR_PHASE_BLOCKS)
-            for (int i = 0; i < 3; ++i) g_phase_cycles[orig * 16 + 8 + i] = ph[i];
-#endif
-        return;
-    }
-
-    // ---- MFMA wave ------------------------------------------------------------------------------------------------
-    const int wm = wave / WN, wn = wave % WN;
-    const int l16 = lane & 15, oct = lane >> 4;                // A: row = l16, k = 8 oct ..; B: column = l16, same k
-    f32x4 acc[RT][CT];
-#pragma unroll
-    for (int i = 0; i < RT; ++i)
-#pragma unroll
-        for (int j = 0; j < CT; ++j)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
-
-#ifdef ASR_GEMM_PHASE_PROFILE
-    long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    long long tprev = (long long)__builtin_readcyclecounter();
-#endif
-    __builtin_amdgcn_s_barrier();                              // stage 0 landed (the loaders waited for it)
-    PHASE_MARK(0);
-#ifdef ASR_GEMM_PHASE_PROFILE
-    const long long loop_c0 = (long long)__builtin_readcyclecounter(), loop_r0 = (long long)__builtin_amdgcn_s_memrealtime();
-#endif
-    for (int kt = 0; kt < KT; ++kt) {
-        const char* const st = lds + (kt & 1) * STAGE_BYTES;
-        // 2 halves x 8 column tiles = 16 groups of 6 MFMAs; the fragments of group g + 1 are requested before the MFMAs of
-        // group g (one B double buffer, the A pair of the second half is requested under the last group of the first),
-        // and a scheduling barrier per group keeps the compiler from hoisting every read to the top (it would need 160
-        // fragment registers and spill).
-        f16x8 ah[2], al[2], bh[2], bl[2];
-        auto read_a = [&](int half, int i) {                   // hi / lo fragments of row tile 2 * half + i
-            const int row = (wm * RT + 2 * half + i) * 16 + l16, swz = (row >> 1) & 7;
-            ah[i] = *reinterpret_cast<const f16x8*>(st + row * 128 + ((oct ^ swz) << 4));
-            al[i] = *reinterpret_cast<const f16x8*>(st + row * 128 + (((4 + oct) ^ swz) << 4));
-        };
-        auto read_b = [&](int j, int buf) {
-            const int col = (wn * CT + j) * 16 + l16;
-            bh[buf] = *reinterpret_cast<const f16x8*>(st + A_BYTES + (oct * BN + col) * 16);
-            bl[buf] = *reinterpret_cast<const f16x8*>(st + A_BYTES + B_BYTES + (oct * BN + col) * 16);
-        };
-        read_a(0, 0);
-        read_a(0, 1);
-        read_b(0, 0);
-        auto group = [&](auto G) {
-            constexpr int g = decltype(G)::value, half = g / CT, j = g % CT;
-            constexpr bool last_of_half0 = g == CT - 1;
-            if (g + 1 < 2 * CT) read_b((g + 1) % CT, (g + 1) & 1);
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                f32x4& a4 = acc[2 * half + i][j];
-                a4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh[g & 1], a4, 0, 0, 0);
-                a4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl[g & 1], a4, 0, 0, 0);
-                a4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bh[g & 1], a4, 0, 0, 0);
-                if (last_of_half0) read_a(1, i);               // the second half's row tile into the registers just consumed
-            }
-            // order inside the group: the next group's fragment reads first, then the MFMAs (the A refills behind their rows)
-            if (g + 1 < 2 * CT) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
-            if (last_of_half0) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
-            if (last_of_half0) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        };
-        asr_static_for<2 * CT>(group);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // this wave's reads of the stage are done
-        PHASE_MARK(2);
-        __builtin_amdgcn_s_barrier();
-        PHASE_MARK(6);
-    }
-#ifdef ASR_GEMM_PHASE_PROFILE
-    if (tid == 0 && orig < ASR_PHASE_BLOCKS) {
-        g_phase_cycles[orig * 16 + 11] = (long long)__builtin_readcyclecounter() - loop_c0;
-        g_phase_cycles[orig * 16 + 12] = (long long)__builtin_amdgcn_s_memrealtime() - loop_r0;
-    }
-#endif
-    if (!(p.debug & 1)) pw_epilogue16<4, WN, RT, CT, true>(p, acc, smem, tile_m, tile_n, wave, lane);
-#ifdef ASR_GEMM_PHASE_PROFILE
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    PHASE_MARK(7);
-    if (tid == 0 && orig < ASR_PHASE_BLOCKS)
-        for (int i = 0; i < 8; ++i) g_phase_cycles[orig * 16 + i] = ph[i];
-#endif
-}
-
-// =================================================================================================
-// Three-stage form of the pre-split kernel: 256 x 128 tile (8 waves of 64 x 64, 16 v_mfma_f32_16x16x32_f16 tiles each),
-// three 48 KB LDS stages, the DMA requests run TWO K-steps ahead, and the two waves that share a SIMD take opposite
-// orders: waves 0-3 request their 6 pieces of K-step kt + 2 BEFORE their 48 MFMAs of K-step kt, waves 4-7 AFTER theirs.
-// tools/ubench_glds_mfma.hip shows what this buys: a wave's MFMAs run at the pipe's rate (32.0 cycles per 32 Kflop)
-// whether or not the SIMD's other wave is issuing LDS-DMA pieces, while the issuing wave pays ~160 cycles per piece --
-// so one wave of a SIMD can sit in the vector-memory queue for free as long as its partner owns the matrix pipe.  The
-// two-stage kernel cannot do this (a late request would have to land within the same K-step); the third stage is what
-// the smaller tile buys.  Waits are counted (vmcnt(6): only the pieces requested in the current K-step may be in flight).
-// =================================================================================================
-template <int N> __device__ __forceinline__ void asr_wait_vmcnt() {
-    __builtin_amdgcn_s_waitcnt((N & 15) | ((N >> 4) << 14) | (7 << 4) | (15 << 8));
-}
-
-__global__ __launch_bounds__(512, 2) void pw_gemm_f16x3_pre3_kernel(PwArgs p) {
-    constexpr int NT = 512, BM = 256, BN = 128, RT = 4, CT = 4, WN = 2;
-    constexpr int A_BYTES = BM * 128, B_BYTES = 4 * BN * 16, STAGE_BYTES = A_BYTES + 2 * B_BYTES;     // 32 + 8 + 8 KB
-    constexpr int PA = BM * 8 / NT;                            // 4 A pieces per thread; B: one per thread and plane
-    constexpr int PIECES = PA + 2;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    char* const lds = reinterpret_cast<char*>(smem);
-
-    const int nwg = gridDim.x, orig = blockIdx.x;
-    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
-    const int lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
-    const int tile_m = lid / p.tiles_n, tile_n = lid % p.tiles_n;
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / WN, wn = wave % WN;
-    const int l16 = lane & 15, oct = lane >> 4;
-    const bool early = wave < 4;                               // waves w and w + 4 share SIMD w % 4
-
-    const char* a_src[PA];
-#pragma unroll
-    for (int i = 0; i < PA; ++i) {
-        const int q = tid + NT * i, row = q >> 3, slot = (q & 7) ^ ((row >> 1) & 7);
-        long long m = (long long)tile_m * BM + row;
-        if (m >= p.M) m = p.M - 1;
-        a_src[i] = reinterpret_cast<const char*>(p.x) + (m * p.ldx) * 128 + slot * 16;           // + kt * 128 per K chunk
-    }
-    const long long plane_bytes = (long long)p.Kpad * p.Npad * 2;
-    const char* const b_src = reinterpret_cast<const char*>(p.wp) + (((long long)(tid >> 7) * p.Npad) + (long long)tile_n * BN + (tid & 127)) * 16;
-    const long long b_kstep = (long long)4 * p.Npad * 16;
-
-    auto issue = [&](int kt) {
-        char* const st = lds + (kt % 3) * STAGE_BYTES;
-#pragma unroll
-        for (int i = 0; i < PA; ++i) glds16(a_src[i] + (long long)kt * 128, st + (wave * 64 + NT * i) * 16);
-        glds16(b_src + kt * b_kstep, st + A_BYTES + wave * 64 * 16);
-        glds16(b_src + kt * b_kstep + plane_bytes, st + A_BYTES + B_BYTES + wave * 64 * 16);
-    };
-
-    f32x4 acc[RT][CT];
-#pragma unroll
-    for (int i = 0; i < RT; ++i)
-#pragma unroll
-        for (int j = 0; j < CT; ++j)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
-
-    const int KT = p.Kpad / BK;
-    issue(0);
-    if (KT > 1) issue(1);
-    if (KT > 1) asr_wait_vmcnt<PIECES>(); else asr_wait_vmcnt<0>();      // K-step 0 landed; K-step 1 may still be in flight
-    __builtin_amdgcn_s_barrier();
-    for (int kt = 0; kt < KT; ++kt) {
-        const char* const st = lds + (kt % 3) * STAGE_BYTES;
-        const bool more2 = kt + 2 < KT;
-        if (early && more2) issue(kt + 2);
-        __builtin_amdgcn_sched_barrier(0);
         f16x8 ah[RT], al[RT];
 #pragma unroll
         for (int i = 0; i < RT; ++i) {
@@ -1043,20 +678,31 @@ __global__ __launch_bounds__(512, 2) void pw_gemm_f16x3_pre3_kernel(PwArgs p) {
             const f16x8 bl = *reinterpret_cast<const f16x8*>(st + A_BYTES + B_BYTES + (oct * BN + col) * 16);
 #pragma unroll
             for (int i = 0; i < RT; ++i) {
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh, acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl, acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bh, acc[i][j], 0, 0, 0);
+                f32x4& a4 = acc[i][j];
+                a4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh, a4, 0, 0, 0);
+                a4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl, a4, 0, 0, 0);
+                a4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bh, a4, 0, 0, 0);
             }
         }
-        __builtin_amdgcn_sched_barrier(0);
-        if (!early && more2) issue(kt + 2);
-        // K-step kt + 1 must have landed before anyone reads it: everything but the pieces requested in THIS K-step
-        if (more2) asr_wait_vmcnt<PIECES>();
-        else asr_wait_vmcnt<0>();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // this wave's LDS reads of the stage are done
-        __builtin_amdgcn_s_barrier();
+        PHASE_MARK(2);
+        PHASE_WAIT_VM();
+        PHASE_MARK(3);
+        __syncthreads();                                       // next stage landed (vmcnt(0)) and everyone is done reading this one
+        PHASE_MARK(6);
     }
-    if (!(p.debug & 1)) pw_epilogue16<4, WN, RT, CT>(p, acc, smem, tile_m, tile_n, wave, lane);
+#ifdef ASR_GEMM_PHASE_PROFILE
+    if (tid == 0 && orig < ASR_PHASE_BLOCKS) {
+        g_phase_cycles[orig * 16 + 11] = (long long)__builtin_readcyclecounter() - loop_c0;
+        g_phase_cycles[orig * 16 + 12] = (long long)__builtin_amdgcn_s_memrealtime() - loop_r0;
+    }
+#endif
+    pw_epilogue16<WM, WN, RT, CT>(p, acc, smem, tile_m, tile_n, wave, lane);
+#ifdef ASR_GEMM_PHASE_PROFILE
+    PHASE_WAIT_VM();
+    PHASE_MARK(7);
+    if (tid == 0 && orig < ASR_PHASE_BLOCKS)
+        for (int i = 0; i < 8; ++i) g_phase_cycles[orig * 16 + i] = ph[i];
+#endif
 }
 
 // w [K][N] f32 -> two half planes [Kpad/8][Npad][8] (hi then lo), zero padded
@@ -1087,12 +733,10 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restri
     }
 }
 
-template <int WM, int WN, int TM, int TN, bool CONV, bool DBUF>
+template <int WM, int WN, int TM, int TN, bool CONV>
 int launch(const PwArgs& a, hipStream_t s) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     PwArgs p = a;
-    static const int dbg = getenv("ASR_GEMM_DEBUG") ? atoi(getenv("ASR_GEMM_DEBUG")) : 0;
-    p.debug = dbg;
     p.tiles_n = (int)asr_cdiv(p.N, BN);
     const long long tiles_m = asr_cdiv(p.M, BM);
     const long long nwg = tiles_m * p.tiles_n;
@@ -1100,13 +744,10 @@ int launch(const PwArgs& a, hipStream_t s) {
         asr_set_error("asr_pwconv_mfma_f32: grid too large (%lld workgroups)", nwg);
         return ASR_ERR_INVALID_ARG;
     }
-    const size_t lds = sizeof(float) * (DBUF ? 2 : 1) * (BM * BK + BK * BN);
-    auto kern = pw_gemm_kernel<WM, WN, TM, TN, CONV, DBUF>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        ASR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    const size_t lds = sizeof(float) * (BM * BK + BK * BN);
+    auto kern = pw_gemm_kernel<WM, WN, TM, TN, CONV>;
+    static AsrDeviceOnce once;
+    ASR_HIP_CHECK(asr_allow_dynamic_lds(once, reinterpret_cast<const void*>(kern), (int)lds));
     hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(256), lds, s, p);
     ASR_LAUNCH_CHECK();
     return ASR_OK;
@@ -1114,18 +755,9 @@ int launch(const PwArgs& a, hipStream_t s) {
 
 template <bool CONV>
 int dispatch(const PwArgs& a, hipStream_t s) {
-    // Single LDS buffer (32 KB at 128x128): 5 blocks = 5 waves per SIMD hide the staging barriers better
-    // than the double-buffered form at 2 blocks per CU (measured +9 % on the whole forward pass).
-    // ASR_GEMM_VARIANT=2 selects the double-buffered kernels for A/B runs.
-    static const int variant = getenv("ASR_GEMM_VARIANT") ? atoi(getenv("ASR_GEMM_VARIANT")) : 0;
-    if (variant == 2) {
-        if (a.N <= 32) return launch<4, 1, 1, 1, CONV, true>(a, s);
-        if (a.N <= 64) return launch<2, 2, 2, 1, CONV, true>(a, s);
-        return launch<2, 2, 2, 2, CONV, true>(a, s);
-    }
-    if (a.N <= 32) return launch<4, 1, 1, 1, CONV, false>(a, s);
-    if (a.N <= 64) return launch<2, 2, 2, 1, CONV, false>(a, s);
-    return launch<2, 2, 2, 2, CONV, false>(a, s);
+    if (a.N <= 32) return launch<4, 1, 1, 1, CONV>(a, s);
+    if (a.N <= 64) return launch<2, 2, 2, 1, CONV>(a, s);
+    return launch<2, 2, 2, 2, CONV>(a, s);
 }
 
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
@@ -1218,47 +850,33 @@ extern "C" int asr_pwconv_pack_weights_f16x3(const float* w_kn, float* w_packed,
     return ASR_OK;
 }
 
-// Launch of the split-f16 kernels (shared by the pointwise and the 3x3 implicit-GEMM entry points).
-static int launch_f16x3(PwArgs a, int forced_shape, asr_stream_t stream) {
-    // Tile shape: 128x128 (4 waves of 64x64, one LDS stage, 3 workgroups per CU) everywhere.  Measured alternatives
-    // (ASR_F16X3_VARIANT, kept for experiments): 2 = 256x256, 8 waves of 64x128, two LDS stages, one workgroup per CU;
-    // 3 = 128x256, 4 waves of 64x128, two workgroups per CU.  Both stage fewer bytes per flop and came out within +-3 % of
-    // 128x128 (and 10-15 % behind it on the 728-channel middle flow): see DESIGN.md "GEMM phase profile".
-    static const int dbg = getenv("ASR_GEMM_DEBUG") ? atoi(getenv("ASR_GEMM_DEBUG")) : 0;
-    static const int variant = getenv("ASR_F16X3_VARIANT") ? atoi(getenv("ASR_F16X3_VARIANT")) : 0;
-    a.debug = dbg;
-    int shape = forced_shape ? forced_shape : (variant ? variant : 1);
-    if ((shape == 2 || shape == 3) && a.Npad % 256 != 0) shape = 1;
-    long long nwg = 0;
-#define ASR_F16X3_LAUNCH(WM_, WN_, TM_, TN_, DBUF_, MINW_, CONV_)                                                                    \
-    do {                                                                                                                 \
-        constexpr int bm = WM_ * TM_ * 32, bn = WN_ * TN_ * 32;                                                          \
-        constexpr size_t lds_stage = (size_t)(DBUF_ ? 2 : 1) * 2 * BK * (bm + bn) * sizeof(_Float16);                    \
-        constexpr size_t lds_epi = (size_t)WM_ * WN_ * 32 * TN_ * 32 * sizeof(float);                                    \
-        constexpr size_t lds = lds_stage > lds_epi ? lds_stage : lds_epi;                                                \
-        a.tiles_n = (int)asr_cdiv(a.N, bn);                                                                                \
-        nwg = asr_cdiv(a.M, bm) * a.tiles_n;                                                                               \
-        ASR_REQUIRE(nwg <= 0x7fffffffLL, "asr_pwconv_mfma_f16x3: grid too large");                                       \
-        auto kern = pw_gemm_f16x3_kernel<WM_, WN_, TM_, TN_, DBUF_, MINW_, CONV_>;                                              \
-        if (lds > 64 * 1024) {                                                                                           \
-            static bool attr_set = false;                                                                                \
-            if (!attr_set) {                                                                                             \
-                ASR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                   \
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                \
-                attr_set = true;                                                                                         \
-            }                                                                                                            \
-        }                                                                                                                \
-        hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(WM_ * WN_ * 64), lds, asr_stream(stream), a);                 \
-    } while (0)
-    switch (shape) {
-        case 2: ASR_F16X3_LAUNCH(4, 2, 2, 4, true, 2, false); break;
-        case 3: ASR_F16X3_LAUNCH(2, 2, 2, 4, false, 2, false); break;
-        case 8: ASR_F16X3_LAUNCH(2, 2, 2, 2, false, 1, true); break;      // 3x3 implicit GEMM, 128 x 128 tile
-        case 9: ASR_F16X3_LAUNCH(2, 2, 2, 1, false, 1, true); break;      // 3x3 implicit GEMM, 128 x 64 tile (cout <= 64)
-        default: ASR_F16X3_LAUNCH(2, 2, 2, 2, false, 1, false); break;
-    }
-#undef ASR_F16X3_LAUNCH
+// Launch of the in-kernel-split kernels (shared by the pointwise and the 3x3 implicit-GEMM entry points): 128 x 128 tile
+// (4 waves of 64 x 64, one LDS stage, 3 workgroups per CU); conv = 0 pointwise, 1 implicit 3x3 GEMM, 2 the same with a
+// 128 x 64 tile (cout <= 64).  Larger tiles of this kernel (256 x 256, 128 x 256) were measured within +-3 % and 10-15 %
+// behind on the 728-channel layers and are not built.
+template <int WM, int WN, int TM, int TN, bool CONV>
+static int launch_f16x3_shape(PwArgs& a, long long& nwg, asr_stream_t stream) {
+    constexpr int bm = WM * TM * 32, bn = WN * TN * 32;
+    constexpr size_t lds_stage = (size_t)2 * BK * (bm + bn) * sizeof(_Float16);
+    constexpr size_t lds_epi = (size_t)WM * WN * 32 * TN * 32 * sizeof(float);
+    constexpr size_t lds = lds_stage > lds_epi ? lds_stage : lds_epi;
+    a.tiles_n = (int)asr_cdiv(a.N, bn);
+    nwg = asr_cdiv(a.M, bm) * a.tiles_n;
+    ASR_REQUIRE(nwg <= 0x7fffffffLL, "asr_pwconv_mfma_f16x3: grid too large");
+    auto kern = pw_gemm_f16x3_kernel<WM, WN, TM, TN, CONV>;
+    static AsrDeviceOnce once;
+    ASR_HIP_CHECK(asr_allow_dynamic_lds(once, reinterpret_cast<const void*>(kern), (int)lds));
+    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(WM * WN * 64), lds, asr_stream(stream), a);
     ASR_LAUNCH_CHECK();
+    return ASR_OK;
+}
+
+static int launch_f16x3(PwArgs a, int conv, asr_stream_t stream) {
+    long long nwg = 0;
+    const int rc = conv == 0 ? launch_f16x3_shape<2, 2, 2, 2, false>(a, nwg, stream)
+                 : conv == 1 ? launch_f16x3_shape<2, 2, 2, 2, true>(a, nwg, stream)
+                             : launch_f16x3_shape<2, 2, 2, 1, true>(a, nwg, stream);
+    if (rc != ASR_OK) return rc;
 #ifdef ASR_GEMM_PHASE_PROFILE
     {
         static long long host[ASR_PHASE_BLOCKS * 16];
@@ -1314,72 +932,16 @@ extern "C" int asr_pwconv_mfma_f16x3_presplit(const void* x_split, const float* 
     a.ldx = ldx_chunks; a.ldy = ldy; a.ldres = ldres; a.relu = relu;
     a.taps = 1; a.cin = k; a.stride = 1; a.pad = 0; a.dil = 1;
     ASR_REQUIRE(ldx_chunks * BK >= a.Kpad, "asr_pwconv_mfma_f16x3_presplit: ldx_chunks * 32 < ceil32(k)");
-    // ASR_PRE_KERNEL=3: the three-stage 256 x 128 kernel (any n); default: the two-stage 256 x 256 kernel
-    static const bool three = getenv("ASR_PRE_KERNEL") && atoi(getenv("ASR_PRE_KERNEL")) == 3;
-    if (three) {
-        ASR_UNSUPPORTED(reinterpret_cast<uintptr_t>(x_split) & 127, "asr_pwconv_mfma_f16x3_presplit: x_split must be 128-byte aligned");
-        static const int dbg3 = getenv("ASR_GEMM_DEBUG") ? atoi(getenv("ASR_GEMM_DEBUG")) : 0;
-        a.debug = dbg3;
-        a.tiles_n = (int)asr_cdiv(n, 128);
-        const long long nwg3 = asr_cdiv(m, 256) * a.tiles_n;
-        ASR_REQUIRE(nwg3 <= 0x7fffffffLL, "asr_pwconv_mfma_f16x3_presplit: grid too large");
-        constexpr size_t lds3 = 3 * (256 * 128 + 2 * 4 * 128 * 16);
-        static bool attr3 = false;
-        if (!attr3) {
-            ASR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pw_gemm_f16x3_pre3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
-            attr3 = true;
-        }
-        hipLaunchKernelGGL(pw_gemm_f16x3_pre3_kernel, dim3((unsigned)nwg3), dim3(512), lds3, asr_stream(stream), a);
-        ASR_LAUNCH_CHECK();
-        return ASR_OK;
-    }
     ASR_UNSUPPORTED(a.Npad % 256 != 0, "asr_pwconv_mfma_f16x3_presplit: ceil128(n) must be a multiple of 256 (n=%d)", n);
     ASR_UNSUPPORTED(reinterpret_cast<uintptr_t>(x_split) & 127, "asr_pwconv_mfma_f16x3_presplit: x_split must be 128-byte aligned");
     constexpr int bm = 256, bn = 256;
-    static const int dbg = getenv("ASR_GEMM_DEBUG") ? atoi(getenv("ASR_GEMM_DEBUG")) : 0;
-    a.debug = dbg;
     a.tiles_n = (int)asr_cdiv(n, bn);
     const long long nwg = asr_cdiv(m, bm) * a.tiles_n;
     ASR_REQUIRE(nwg <= 0x7fffffffLL, "asr_pwconv_mfma_f16x3_presplit: grid too large");
     constexpr size_t lds = 2 * (bm * 128 + 2 * 4 * bn * 16);
-    // (a persistent one-workgroup-per-CU form that requests the next output tile's first K tile before the epilogue of the
-    // current one, staging the epilogue through a single LDS stage, measured equal: -2 % .. +4 %; not kept)
-    static const bool lw = getenv("ASR_PRE_LW") && atoi(getenv("ASR_PRE_LW")) == 1;
-    if (lw) {
-        static bool attr_lw = false;
-        if (!attr_lw) {
-            ASR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pw_gemm_f16x3_pre_lw_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            attr_lw = true;
-        }
-        hipLaunchKernelGGL(pw_gemm_f16x3_pre_lw_kernel<16>, dim3((unsigned)nwg), dim3(768), lds, asr_stream(stream), a);
-        ASR_LAUNCH_CHECK();
-#ifdef ASR_GEMM_PHASE_PROFILE
-        {
-            static long long host[ASR_PHASE_BLOCKS * 16];
-            ASR_HIP_CHECK(hipDeviceSynchronize());
-            ASR_HIP_CHECK(hipMemcpyFromSymbol(host, HIP_SYMBOL(g_phase_cycles), sizeof(host)));
-            const long long nb = nwg < ASR_PHASE_BLOCKS ? nwg : ASR_PHASE_BLOCKS;
-            double mean[16] = {0};
-            for (long long b = 0; b < nb; ++b)
-                for (int i = 0; i < 16; ++i) mean[i] += (double)host[b * 16 + i] / (double)nb;
-            const int kt = a.Kpad / 32;
-            fprintf(stderr, "[phase-lw] M=%lld K=%d N=%d blocks=%lld ksteps=%d | mfma wave 0: prologue %.0f | per k-step: reads+mfma %.0f  barrier %.0f | "
-                            "epilogue %.0f || loader wave 8 per k-step: issue %.0f  landing wait %.0f  barrier %.0f || K loop %.0f cycles = %.2f us -> "
-                            "%.3f GHz, per k-step %.0f\n", (long long)a.M, a.K, a.N, nwg, kt, mean[0], mean[2] / kt, mean[6] / kt, mean[7], mean[8] / kt,
-                    mean[9] / kt, mean[10] / kt, mean[11], mean[12] / 100.0, mean[12] > 0 ? mean[11] / (mean[12] * 10.0) : 0.0, mean[11] / kt);
-        }
-#endif
-        return ASR_OK;
-    }
-    // ASR_PRE_MFMA=32: the v_mfma_f32_32x32x16_f16 form (bit-identical to the in-kernel-split kernel) instead of 16x16x32
-    static const bool m32 = getenv("ASR_PRE_MFMA") && atoi(getenv("ASR_PRE_MFMA")) == 32;
-    static const bool hl = getenv("ASR_PRE_LW") && atoi(getenv("ASR_PRE_LW")) == 2;
-    auto kern = m32 ? pw_gemm_f16x3_pre_kernel<4, 2, 2, 4, false> : (hl ? pw_gemm_f16x3_pre_kernel<4, 2, 2, 4, true, true> : pw_gemm_f16x3_pre_kernel<4, 2, 2, 4, true>);
-    static bool attr_set = false;
-    if (!attr_set) {
-        ASR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    auto kern = pw_gemm_f16x3_pre_kernel<4, 2, 2, 4>;
+    static AsrDeviceOnce once;
+    ASR_HIP_CHECK(asr_allow_dynamic_lds(once, reinterpret_cast<const void*>(kern), (int)lds));
     hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(512), lds, asr_stream(stream), a);
     ASR_LAUNCH_CHECK();
 #ifdef ASR_GEMM_PHASE_PROFILE
@@ -1419,5 +981,5 @@ extern "C" int asr_conv3x3_mfma_f16x3(const float* x, const float* w_packed, con
     a.ldx = ldx; a.ldy = ldy; a.ldres = 0; a.relu = relu;
     a.taps = 9; a.cin = cin; a.h_in = h_in; a.w_in = w_in; a.h_out = h_out; a.w_out = w_out;
     a.stride = stride; a.pad = pad; a.dil = dil;
-    return launch_f16x3(a, cout <= 64 ? 9 : 8, stream);
+    return launch_f16x3(a, cout <= 64 ? 2 : 1, stream);
 }

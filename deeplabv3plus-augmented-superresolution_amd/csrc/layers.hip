@@ -492,16 +492,10 @@ extern "C" int asr_entry_stem_f16x3(const float* x, const float* w1, const float
     ASR_UNSUPPORTED((long long)h_in * w_in * ldx > 0x7fffffffLL, "asr_entry_stem_f16x3: image too large");
     ASR_UNSUPPORTED(reinterpret_cast<uintptr_t>(w2_packed) & 15, "asr_entry_stem_f16x3: w2_packed must be 16-byte aligned");
     const int h1 = h_in / 2, w1d = w_in / 2;
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        ASR_HIP_CHECK(hipGetDevice(&dev));
-        ASR_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
-        cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-        ASR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(entry_stem_fused_kernel),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, ES_LDS_BYTES));
-    }
+    const int cus = asr_device_cu_count();
+    ASR_REQUIRE(cus > 0, "asr_entry_stem_f16x3: cannot query the device");
+    static AsrDeviceOnce once;
+    ASR_HIP_CHECK(asr_allow_dynamic_lds(once, reinterpret_cast<const void*>(entry_stem_fused_kernel), ES_LDS_BYTES));
     const long long tiles = (long long)batch * asr_cdiv(h1, ES_T) * asr_cdiv(w1d, ES_T);
     const int grid = (int)(tiles < cus ? tiles : cus);
     hipLaunchKernelGGL(entry_stem_fused_kernel, dim3(grid), dim3(512), ES_LDS_BYTES, asr_stream(stream), x, w1, b1,

@@ -191,218 +191,14 @@ __global__ __launch_bounds__(512) void sepconv_fused_kernel(const float* __restr
     }
 }
 
-// ---- the same fusion for 256 output channels and any cin % 16 == 0 (block 2 of the entry flow, the decoder) ----------
-// The pointwise weights (cin x 256, hi + lo: up to 320 KB) no longer fit in LDS, so K advances in chunks of 64
-// channels: a chunk's 64 x 256 weight slab arrives by LDS-DMA (global_load_lds, 8 pieces per wave, lane-linear = the
-// [octet][column] image the B fragments read) into one of two slab buffers, its depthwise output is computed into the
-// LDS line image (16 quads x 16 columns, each thread all 8 rows), and 96 MFMAs per wave accumulate it (4 waves, one per
-// SIMD, 32 lines x 256 columns each).  The slab and the input rows of chunk k + 1 are requested before the
-// MFMAs of chunk k, so their latency is hidden; the line image is single-buffered (160 KB of LDS in all).  Same k order
-// and MFMA sequence per accumulator as asr_pwconv_mfma_f16x3_presplit -> bit-identical to the two-kernel form.
-typedef __attribute__((address_space(3))) void* sf_lds_ptr;
-typedef const __attribute__((address_space(1))) void* sf_gbl_ptr;
-
-__global__ __launch_bounds__(256) void sepconv_fused_stream_kernel(const float* __restrict__ x, const float* __restrict__ wd,
-                                                                   const float* __restrict__ bd, const _Float16* __restrict__ wp,
-                                                                   const float* __restrict__ bp, float* __restrict__ y, int batch,
-                                                                   int h, int w, int cin, int kpad, int ldx, int ldy, int pre_relu,
-                                                                   int dw_relu, int out_relu) {
-    constexpr int KC = 64, N = 256, RPT = SF_TH, TN = 8;      // channels per chunk; output channels; rows per thread; 32-column tiles per wave
-    constexpr int LB = KC * 4, OCTS = KC / 8;                 // 256-byte lines: 8 hi slots + 8 lo slots
-    constexpr int A_BYTES = SF_M * LB, B_BYTES = OCTS * N * 16;      // 32 KB; 32 KB per plane, two planes, two slabs
-    extern __shared__ __attribute__((aligned(16))) char sf_lds[];
-    char* const A = sf_lds;
-    char* const Bbase = sf_lds + A_BYTES;                      // slab s: hi plane at Bbase + 2 s B_BYTES, lo plane B_BYTES later
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l32 = lane & 31, hh = lane >> 5;
-    const int lane16 = lane & 15, slot = wave * 4 + (lane >> 4);
-    // 4 waves, one per SIMD (up to 512 registers each: 128 accumulators + two sets of input rows in flight): a 16-lane
-    // row = (channel quad q, 16 columns), every thread marches down all 8 rows of the tile; wave wm owns 32 lines x 256 columns
-    const int q = slot, ry0 = 0;
-    const int wm = wave;
-    float bpv[TN];
-#pragma unroll
-    for (int j = 0; j < TN; ++j) bpv[j] = bp[j * 32 + l32];
-    const long long plane = (long long)kpad * N;              // halfs between the hi and the lo plane of the packed weights
-    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-    const int nchunks = (cin + KC - 1) / KC;
-
-    // the weight slab of chunk kc (octets 8 kc .. 8 kc + 7, 256 columns, both planes): this wave's 8 + 8 LDS-DMA pieces
-    auto request_slab = [&](int kc) {
-        char* const Bh = Bbase + (kc & 1) * 2 * B_BYTES;
-        const _Float16* src = wp + ((long long)(kc * OCTS) * N) * 8 + (wave * 8 * 64 + lane) * 8;
-#pragma unroll
-        for (int pz = 0; pz < 8; ++pz) {
-            __builtin_amdgcn_global_load_lds((sf_gbl_ptr)(src + pz * 64 * 8), (sf_lds_ptr)(Bh + (wave * 8 + pz) * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((sf_gbl_ptr)(src + plane + pz * 64 * 8), (sf_lds_ptr)(Bh + B_BYTES + (wave * 8 + pz) * 1024), 16, 0, 0);
-        }
-    };
-
-    const int tiles_x = (w + SF_TW - 1) / SF_TW, tiles_y = (h + SF_TH - 1) / SF_TH;
-    const long long total = (long long)batch * tiles_y * tiles_x;
-    for (long long tile = blockIdx.x; tile < total; tile += gridDim.x) {
-        const int x0 = (int)(tile % tiles_x) * SF_TW;
-        const long long tt = tile / tiles_x;
-        const int y0 = (int)(tt % tiles_y) * SF_TH;
-        const long long b = tt / tiles_y;
-        const int ix = x0 - 1 + lane16;
-        const bool col_ok = ix >= 0 && ix < w;
-        const int ixc = min(max(ix, 0), w - 1);
-        const float* const ximg = x + b * h * w * ldx;
-
-        // the RPT + 2 input rows of chunk kc for this thread (requests only; consumed by depthwise())
-        auto request_rows = [&](int kc, f32x4 (&in)[RPT + 2]) {
-            const int ch = kc * KC + q * 4;
-            const float* xin = ximg + (ch < cin ? ch : 0);
-#pragma unroll
-            for (int r = 0; r < RPT + 2; ++r) {
-                const int iy = min(max(y0 + ry0 - 1 + r, 0), h - 1);
-                in[r] = *reinterpret_cast<const f32x4*>(xin + ((long long)iy * w + ixc) * ldx);
-            }
-        };
-        // depthwise of chunk kc from the requested rows -> split-f16 lines of the LDS image
-        auto depthwise = [&](int kc, const f32x4 (&in)[RPT + 2]) {
-            const int ch = kc * KC + q * 4;
-            const bool ch_ok = ch < cin;                       // cin % 16 == 0 but not % 64: the last chunk's upper quads are padding
-            const int chc = ch_ok ? ch : 0;
-            f32x4 wk[9];
-#pragma unroll
-            for (int t = 0; t < 9; ++t) wk[t] = *reinterpret_cast<const f32x4*>(wd + t * cin + chc);
-            const f32x4 bv = *reinterpret_cast<const f32x4*>(bd + chc);
-            // Accumulate-on-arrival: input row r contributes its ky = 0 / 1 / 2 terms to output rows r, r - 1, r - 2, whose
-            // partial sums live in a ring of three registers quads -- the same order of additions per output (bias, then
-            // ky = 0, 1, 2 with kx = 0, 1, 2 inside) as the window form, a third fewer live registers.
-            f32x4 part[3];
-#pragma unroll
-            for (int r = 0; r < RPT + 2; ++r) {
-                const int iy = y0 + ry0 - 1 + r;
-                f32x4 c = in[r];
-                if (pre_relu) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) c[i] = fmaxf(c[i], 0.f);
-                }
-                c = (col_ok && iy >= 0 && iy < h) ? c : zero;
-                const f32x4 l = sf_dpp4<0x111>(c), rr = sf_dpp4<0x101>(c);
-                if (r < RPT) {                                 // first row of output r's window
-                    f32x4 acc = bv;
-                    acc += l * wk[0];
-                    acc += c * wk[1];
-                    acc += rr * wk[2];
-                    part[r % 3] = acc;
-                }
-                if (r >= 1 && r - 1 < RPT) {
-                    f32x4 acc = part[(r - 1) % 3];
-                    acc += l * wk[3];
-                    acc += c * wk[4];
-                    acc += rr * wk[5];
-                    part[(r - 1) % 3] = acc;
-                }
-                if (r >= 2) {
-                    f32x4 acc = part[(r - 2) % 3];
-                    acc += l * wk[6];
-                    acc += c * wk[7];
-                    acc += rr * wk[8];
-                    if (dw_relu) {
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) acc[i] = fmaxf(acc[i], 0.f);
-                    }
-                    if (!ch_ok) acc = zero;                    // padding channels: zero lines (the packed weights are zero there too)
-                    f16x4 hi, lo;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const _Float16 hf = (_Float16)acc[i];
-                        hi[i] = hf;
-                        lo[i] = (_Float16)(acc[i] - (float)hf);
-                    }
-                    if (lane16 >= 1 && lane16 <= SF_TW) {
-                        const int line = (ry0 + r - 2) * SF_TW + lane16 - 1;
-                        char* const base = A + line * LB + (q & 1) * 8;
-                        *reinterpret_cast<f16x4*>(base + sf_swz(q >> 1, line) * 16) = hi;
-                        *reinterpret_cast<f16x4*>(base + sf_swz(OCTS + (q >> 1), line) * 16) = lo;
-                    }
-                }
-            }
-        };
-
-        f32x16 acc2[TN];
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc2[j][e] = 0.0f;
-        __syncthreads();                                      // the previous tile's last MFMAs are done with A and the slabs
-        request_slab(0);
-        {
-            f32x4 in0[RPT + 2];
-            request_rows(0, in0);
-            depthwise(0, in0);
-        }
-        __syncthreads();                                      // lines of chunk 0 written, slab 0 landed (vmcnt(0) + barrier)
-        for (int kc = 0; kc < nchunks; ++kc) {
-            const bool more = kc + 1 < nchunks;
-            f32x4 inn[RPT + 2];
-            if (more) {                                        // the next chunk's weights and input rows fly under this chunk's MFMAs
-                request_slab(kc + 1);
-                request_rows(kc + 1, inn);
-            }
-            // ---- stage 2: 32 lines x 256 columns x 64 channels ----
-            const char* const Bh = Bbase + (kc & 1) * 2 * B_BYTES;
-            const char* const Bl = Bh + B_BYTES;
-            const int m = wm * 32 + l32;
-            const char* const aline = A + m * LB;
-#pragma unroll
-            for (int kk = 0; kk < KC / 16; ++kk) {
-                const int oct = 2 * kk + hh;
-                const f16x8 ah = *reinterpret_cast<const f16x8*>(aline + sf_swz(oct, m) * 16);
-                const f16x8 al = *reinterpret_cast<const f16x8*>(aline + sf_swz(OCTS + oct, m) * 16);
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    const int col = j * 32 + l32;
-                    const f16x8 bh = *reinterpret_cast<const f16x8*>(Bh + (oct * N + col) * 16);
-                    const f16x8 bl = *reinterpret_cast<const f16x8*>(Bl + (oct * N + col) * 16);
-                    acc2[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc2[j], 0, 0, 0);
-                    acc2[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc2[j], 0, 0, 0);
-                    acc2[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc2[j], 0, 0, 0);
-                }
-            }
-            if (more) {
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();                  // everyone has read this chunk's lines: A may be overwritten
-                depthwise(kc + 1, inn);
-                __syncthreads();                              // next lines written, next slab landed
-            }
-        }
-        float* const ybase = y + (b * h * w) * ldy + l32;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int line = wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
-            const int ty = line / SF_TW, tx = line - ty * SF_TW;
-            const int oy = y0 + ty, ox = x0 + tx;
-            if (line < SF_VALID && oy < h && ox < w) {
-                float* const o = ybase + ((long long)oy * w + ox) * ldy;
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    float v = acc2[j][e] + bpv[j];
-                    if (out_relu) v = fmaxf(v, 0.f);
-                    o[j * 32] = v;
-                }
-            }
-        }
-    }
-}
-
 template <int CIN>
 int launch_sepconv_fused(const float* x, const float* wd, const float* bd, const void* wp, const float* bp, float* y, int batch,
                          int h, int w, int ldx, int ldy, int npad, int pre_relu, int dw_relu, int out_relu, hipStream_t s) {
     constexpr int lds = SF_M * CIN * 4 + 2 * (CIN / 8) * SF_N * 16;        // 128 KB (cin 128) / 64 KB (cin 64)
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        ASR_HIP_CHECK(hipGetDevice(&dev));
-        ASR_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
-        ASR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(sepconv_fused_kernel<CIN>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
+    const int cus = asr_device_cu_count();
+    ASR_REQUIRE(cus > 0, "asr_sepconv_fused_f16x3: cannot query the device");
+    static AsrDeviceOnce once;
+    ASR_HIP_CHECK(asr_allow_dynamic_lds(once, reinterpret_cast<const void*>(sepconv_fused_kernel<CIN>), lds));
     const long long tiles = (long long)batch * asr_cdiv(h, SF_TH) * asr_cdiv(w, SF_TW);
     const long long want = (long long)cus * (lds <= 80 * 1024 ? 2 : 1);
     const int grid = (int)(tiles < want ? tiles : want);
@@ -419,34 +215,13 @@ extern "C" int asr_sepconv_fused_f16x3(const float* x, const float* w_dw, const 
                                        int ldy, int pre_relu, int dw_relu, int out_relu, asr_stream_t stream) {
     ASR_REQUIRE(x && w_dw && bias_dw && w_pw_packed && bias_pw && y, "asr_sepconv_fused_f16x3: null pointer");
     ASR_REQUIRE(batch > 0 && h > 0 && w > 0 && ldx >= cin && ldy >= cout, "asr_sepconv_fused_f16x3: bad geometry");
-    ASR_UNSUPPORTED(!(((cin == 64 || cin == 128) && cout == 128) || (cout == 256 && cin % 16 == 0 && cin >= 16)),
-                    "asr_sepconv_fused_f16x3: cin in {64, 128} -> 128, or cin %% 16 == 0 -> 256 (got %d -> %d)", cin, cout);
+    ASR_UNSUPPORTED(!((cin == 64 || cin == 128) && cout == 128),
+                    "asr_sepconv_fused_f16x3: cin in {64, 128} -> 128 only (got %d -> %d)", cin, cout);
     ASR_UNSUPPORTED((ldx & 3) || ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w_dw) |
                                    reinterpret_cast<uintptr_t>(bias_dw) | reinterpret_cast<uintptr_t>(w_pw_packed)) & 15),
                     "asr_sepconv_fused_f16x3: ldx %% 4 == 0 and 16-byte aligned x / weights required");
     ASR_UNSUPPORTED((long long)h * w * ldx > 0x7fffffffLL, "asr_sepconv_fused_f16x3: image too large");
     hipStream_t s = asr_stream(stream);
-    if (cout == 256) {
-        constexpr int lds = SF_M * 256 + 2 * 2 * 8 * 256 * 16;             // 32 KB of lines + two 64 KB weight slabs = 160 KB
-        static int cus = 0;
-        if (!cus) {
-            int dev = 0;
-            hipDeviceProp_t prop;
-            ASR_HIP_CHECK(hipGetDevice(&dev));
-            ASR_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
-            ASR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(sepconv_fused_stream_kernel),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-            cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-        }
-        const long long tiles = (long long)batch * asr_cdiv(h, SF_TH) * asr_cdiv(w, SF_TW);
-        const int grid = (int)(tiles < cus ? tiles : cus);
-        const int kpad = (cin + 31) / 32 * 32;                             // asr_pwconv_pack_weights_f16x3 pads K to 32
-        hipLaunchKernelGGL(sepconv_fused_stream_kernel, dim3(grid), dim3(256), lds, s, x, w_dw, bias_dw,
-                           reinterpret_cast<const _Float16*>(w_pw_packed), bias_pw, y, batch, h, w, cin, kpad, ldx, ldy, pre_relu,
-                           dw_relu, out_relu);
-        ASR_LAUNCH_CHECK();
-        return ASR_OK;
-    }
     const int npad = 128;
     if (cin == 64)
         return launch_sepconv_fused<64>(x, w_dw, bias_dw, w_pw_packed, bias_pw, y, batch, h, w, ldx, ldy, npad, pre_relu, dw_relu, out_relu, s);

@@ -752,13 +752,10 @@ int check_dims(const char* fn, int batch, int n, int H, int W, int h, int w, SrD
 int prepare_backward(const SrDims& d) {
     const size_t lds = sizeof(float) * (size_t)d.n * 64;
     ASR_UNSUPPORTED(lds > 160 * 1024, "asr_sr: num_aug=%d needs %zu bytes of LDS in the backward kernel (max 640 copies)", d.n, lds);
-    static bool attr_set[4] = {false, false, false, false};
+    static AsrDeviceOnce once[4];
     const int idx = d.f == 2 ? 1 : (d.f == 4 ? 2 : (d.f == 8 ? 3 : 0));
-    if (!attr_set[idx] && lds > 64 * 1024) {
-        ASR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(sr_backward_kernel_for(d.f)),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set[idx] = true;
-    }
+    if (lds > 64 * 1024)
+        ASR_HIP_CHECK(asr_allow_dynamic_lds(once[idx], reinterpret_cast<const void*>(sr_backward_kernel_for(d.f)), 160 * 1024));
     return ASR_OK;
 }
 dim3 gr_grid(const SrDims& d) {

@@ -77,15 +77,27 @@ def _same_pad(in_size, k_eff, stride):
 class DeeplabEngine:
     """Folded / packed parameters on the device + per-(batch, H, W) launch plans."""
 
+    FUSIONS = ("presplit", "fused_stem", "fused_sepconv", "fused_aspp")
+
     def __init__(self, weights: dict, classes=21, device=None, precision=None, backbone="xception", alpha=1.0, OS=16,
-                 decoder="full", first_upsample_size=(128, 128), class_prediction=True):
+                 decoder="full", first_upsample_size=(128, 128), class_prediction=True, disable=None):
         """decoder: "full" | "dcnn" | "aspp" = Decoder / Decoder_only_DCNN / Decoder_only_ASPP (model.py:235-294; the
         last two resize to first_upsample_size instead of the skip's size); class_prediction=False returns the decoder's
         256-channel features instead of the logits (model.py:104-106).
+        disable: names from FUSIONS to leave out of the plan (profiling / A-B runs; default: $ASR_DISABLE, comma separated) --
+        "presplit" (depthwise hands split-f16 operands to the LDS-DMA GEMM), "fused_stem" (conv1_1 + conv1_2 in one kernel),
+        "fused_sepconv" (entry-flow block 1 separable convs in one kernel), "fused_aspp" (three dilation rates from one LDS
+        plane).  Every combination computes the same layers; results agree to f32 rounding.
         precision: 'f32' = v_mfma_f32_32x32x2_f32 everywhere (exact f32 fmaf chains);
         'f16x3' = split-f16 MFMA (hi*hi + hi*lo + lo*hi, f32 accumulate; f32-grade results, ~2.4x faster)
         for the pointwise GEMMs with more than 64 output channels.  Default: $ASR_PRECISION or 'f16x3'."""
         self.device = device or _lib.require_gpu()
+        if disable is None:
+            disable = [v for v in os.environ.get("ASR_DISABLE", "").split(",") if v]
+        unknown = set(disable) - set(self.FUSIONS)
+        if unknown:
+            raise ValueError(f"unknown fusion name(s) {sorted(unknown)}; choose from {self.FUSIONS}")
+        self.disabled = frozenset(disable)
         self.precision = precision or os.environ.get("ASR_PRECISION", "f16x3")
         if self.precision not in ("f32", "f16x3"):
             raise ValueError(f"precision must be 'f32' or 'f16x3', got {self.precision!r}")
@@ -261,13 +273,10 @@ class DeeplabEngine:
             srows = 16 if ho <= 32 else 32
             split_ok = (pp.get("fn", "").endswith("f16x3") and (-(-pp["n"] // 128) * 128) % 256 == 0 and not pw_kw.get("out_off")
                         and pw_kw.get("sub", 1) == 1 and ((stride == 1 and rate in (1, 2)) or (stride == 2 and rate == 1))
-                        and ho % srows == 0 and c % 8 == 0 and b <= 65535 and b * ho * wo >= 256 and not os.environ.get("ASR_NO_PRESPLIT"))
-            fused_ok = (pp.get("fn", "").endswith("f16x3") and stride == 1 and rate == 1
-                        and ((c in (64, 128) and pp["n"] == 128)
-                             # the 256-output streaming form measures equal to the two-kernel form: opt-in
-                             or (pp["n"] == 256 and c % 16 == 0 and os.environ.get("ASR_FUSED_SEPCONV256") == "1"))
+                        and ho % srows == 0 and c % 8 == 0 and b <= 65535 and b * ho * wo >= 256 and "presplit" not in self.disabled)
+            fused_ok = (pp.get("fn", "").endswith("f16x3") and stride == 1 and rate == 1 and c in (64, 128) and pp["n"] == 128
                         and not pw_kw.get("out_off") and pw_kw.get("sub", 1) == 1 and pw_kw.get("res") is None
-                        and pp["b"] is not None and x.ld % 4 == 0 and not os.environ.get("ASR_NO_FUSED_SEPCONV"))
+                        and pp["b"] is not None and x.ld % 4 == 0 and "fused_sepconv" not in self.disabled)
             if fused_ok:
                 # both halves in one kernel: the depthwise output lives in LDS only (entry-flow block 1 at 256 x 256)
                 out = pw_kw.get("out")
@@ -374,7 +383,7 @@ class DeeplabEngine:
         p1, p2 = self.p["entry_flow_conv1_1"], self.p["entry_flow_conv1_2"]
         a2 = new((B, h1, w1, 64))
         if (self.precision == "f16x3" and p2["fn"].endswith("f16x3") and H % 2 == 0 and Wd % 2 == 0
-                and not os.environ.get("ASR_NO_FUSED_STEM")):
+                and "fused_stem" not in self.disabled):
             # conv1_1 + conv1_2 in one kernel: the 32-channel intermediate stays in LDS
             add("asr_entry_stem_f16x3", (x_in.ptr, p1["w"].data_ptr(), p1["b"].data_ptr(), p2["w"].data_ptr(), p2["b"].data_ptr(),
                                          a2.ptr, B, H, Wd, 3, a2.ld), "conv", 2.0 * B * h1 * w1 * (27 * 32 + 288 * 64),
@@ -417,13 +426,13 @@ class DeeplabEngine:
         release(pp)
         pw(x, "aspp0", out=cat, out_off=256, relu=True)
         rates = self.atrous_rates
-        if fh * fw * 128 <= 160 * 1024 and not os.environ.get("ASR_NO_FUSED_ASPP"):
+        if fh * fw * 128 <= 160 * 1024 and "fused_aspp" not in self.disabled:
             # the three dilated depthwise convs read the same input: one fused launch stages each
             # 32-channel plane in LDS once (input read from HBM 1x instead of 3x)
             ts = [new((b, fh, fw, fc)) for _ in rates]
             p3 = self.p["aspp_dw3"]
             split = (all(self.p[f"aspp{i + 1}_pointwise"].get("fn", "").endswith("f16x3") for i in range(3)) and fc % 32 == 0
-                     and b * fh * fw >= 256 and not os.environ.get("ASR_NO_PRESPLIT"))
+                     and b * fh * fw >= 256 and "presplit" not in self.disabled)
             add("asr_aspp_dwconv3_nhwc_split_f16" if split else "asr_aspp_dwconv3_nhwc_f32",
                 (x.ptr, p3["w"].data_ptr(), p3["b"].data_ptr(), ts[0].ptr, ts[1].ptr, ts[2].ptr, b, fh, fw, fc,
                  rates[0], rates[1], rates[2], x.ld, fc // 32 if split else ts[0].ld, 0, 1),

@@ -386,8 +386,7 @@ def entry_stem_fused(x, w1_hwio, b1, w2_packed16, b2):
 
 
 def sepconv_fused(x, w_33c, bias_dw, w_packed16, bias_pw, cout, pre_relu=False, dw_relu=False, out_relu=False):
-    """A whole separable conv (depthwise 3x3 stride 1 + pointwise) in one kernel: cin in {64, 128} -> 128, or
-    cin % 16 == 0 -> 256."""
+    """A whole separable conv (depthwise 3x3 stride 1 + pointwise) in one kernel: cin in {64, 128} -> 128."""
     b, h, w, c = x.shape
     y = torch.empty((b, h, w, cout), dtype=f32, device=x.device)
     call("asr_sepconv_fused_f16x3", ptr(x), ptr(w_33c), ptr(bias_dw), ptr(w_packed16), ptr(bias_pw), ptr(y), b, h, w, c, cout, c,
@@ -430,7 +429,7 @@ def aspp_dwconv3(x, w3, bias3, rates=(6, 12, 18), pre_relu=False, post_relu=True
 
 def dwconv3x3(x, w_33c, bias, stride=1, rate=1, pad_top=None, pad_left=None, out_hw=None, pre_relu=False,
               post_relu=False, force_direct=0, out=None, ldy=None):
-    """force_direct is the kernel mode: 0 auto, 1 direct, 2 streaming register window, 3 LDS-tiled."""
+    """force_direct is the kernel mode: 0 auto, 1 direct, 2 streaming register window."""
     b, h, w, c = x.shape
     if pad_top is None:
         pad_top = pad_left = rate            # stride-1 'same'

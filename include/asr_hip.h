@@ -11,8 +11,9 @@
  *  - every function returns int: ASR_OK (0) or a negative ASR_ERR_*; asr_last_error() returns a
  *    thread-local message for the last failing call on this thread;
  *  - all array pointers are CALLER-OWNED DEVICE pointers (hipMalloc / torch ROCm tensors); the
- *    library allocates nothing and keeps no global mutable state (callable from several host
- *    threads / streams concurrently); scratch space is passed in explicitly;
+ *    library allocates nothing and keeps no unsynchronised global state -- its only caches (a kernel's dynamic-LDS
+ *    allowance, a device's CU count) are per-device atomics, and no environment variable changes which kernel runs --
+ *    so it is callable from several host threads / streams / devices concurrently; scratch space is passed in explicitly;
  *  - every call takes an explicit stream (hipStream_t passed as void*) and is asynchronous
  *    with respect to the host;
  *  - layouts are dense row-major float32, images NHWC; "ld*" arguments are the element stride
@@ -268,8 +269,9 @@ int asr_conv3x3_mfma_f16x3(const float* x, const float* w_packed, const float* b
  * the A-operand format of the split-f16 GEMM -- per pixel and per chunk of 32 channels one 128-byte line
  * [hi(32 halfs) | lo(32 halfs)], hi = f16(v), lo = f16(v - hi): the very split asr_pwconv_mfma_f16x3 applies to the
  * f32 value on its way into LDS, and the same number of bytes -- it lets the GEMM take both operands by LDS-DMA
- * (no staging registers, no conversion work) on a 256 x 256 tile.  Results are bit-identical to
- * asr_dwconv3x3_nhwc_f32 followed by asr_pwconv_mfma_f16x3.
+ * (no staging registers, no conversion work) on a 256 x 256 tile.  Same hi / lo halves, same three products; the 256 x 256
+ * kernel sums each 32-deep K-step in one v_mfma_f32_16x16x32_f16, so it differs from asr_dwconv3x3_nhwc_f32 followed by
+ * asr_pwconv_mfma_f16x3 by f32 summation-order noise only (both within 4e-6 * sum |x||w| of the exact product).
  *
  * asr_dwconv3x3_nhwc_split_f16: asr_dwconv3x3_nhwc_f32 with y in that format; ldy_chunks = ceil(c / 32) chunks per
  * pixel, channels c .. 32 * ldy_chunks - 1 are written as zeros; needs (stride 1, rate 1|2) or (stride 2, rate 1) and
@@ -319,7 +321,7 @@ int asr_sepconv_fused_f16x3(const float* x, const float* w_dw, const float* bias
 /* DepthwiseConv2D 3x3 (+ ZeroPadding2D, folded BN, ReLU before and/or after): the depthwise half
  * of _SepConv_BN, model.py:478-495, and of _inverted_res_block, model.py:442-449 (post_relu = 2: ReLU6).
  * w [3,3,c] with the BN scale folded, bias [c].
- * mode: 0 = auto, 1 = direct, 2 = register-window streaming, 3 = LDS-tiled, 4 = flat streaming (testing / A-B runs). */
+ * mode: 0 = auto, 1 = direct (any stride / rate), 2 = register-window streaming ((stride 1, rate 1|2) or (stride 2, rate 1)). */
 int asr_dwconv3x3_nhwc_f32(const float* x, const float* w, const float* bias, float* y, int batch, int h_in,
                            int w_in, int c, int stride, int rate, int pad_top, int pad_left, int h_out, int w_out,
                            int ldx, int ldy, int pre_relu, int post_relu, int mode, asr_stream_t stream);

@@ -183,9 +183,7 @@ def test_entry_stem_fused_matches_the_two_kernels(dev, b, h, w_):
 
 
 @pytest.mark.parametrize("c,n,b,h,w_,depth_act", [(128, 128, 2, 24, 40, False), (64, 128, 2, 17, 30, False),
-                                                   (128, 128, 1, 8, 14, True), (64, 128, 3, 33, 15, True),
-                                                   (256, 256, 2, 24, 40, False), (128, 256, 1, 19, 30, False),
-                                                   (304, 256, 2, 16, 28, True), (48, 256, 1, 9, 17, True)])
+                                                   (128, 128, 1, 8, 14, True), (64, 128, 3, 33, 15, True)])
 def test_sepconv_fused_is_bit_identical_to_the_two_kernels(dev, c, n, b, h, w_, depth_act):
     """depthwise -> LDS (split f16) -> MFMA GEMM in one kernel against asr_dwconv3x3_nhwc_f32 + asr_pwconv_mfma_f16x3:
     same depthwise arithmetic, same MFMA sequence per accumulator -> bitwise equal; ragged 8 x 14 tiles and image borders."""
@@ -219,10 +217,9 @@ def _dw_ref(x, k, bias, stride, rate, pad, pre, post):
 
 
 @pytest.mark.parametrize("h,w_,c,stride,rate,pre,post,direct", [
-    # last field = kernel mode: 0 auto (streaming where possible), 1 direct, 2 streaming, 3 LDS-tiled
-    (32, 32, 728, 1, 1, True, False, 3),         # middle flow, C not a multiple of 64, LDS-tiled
-    (40, 24, 128, 1, 1, True, False, 3),         # ragged tiles
-    (32, 32, 1536, 1, 2, False, True, 3),        # exit block 2, LDS-tiled
+    # last field = kernel mode: 0 auto (streaming where possible), 1 direct, 2 streaming
+    (32, 32, 728, 1, 1, True, False, 0),         # middle flow, C not a multiple of 64 (auto = streaming)
+    (40, 24, 132, 1, 1, True, False, 0),         # ragged strips and columns, C % 64 != 0
     (32, 32, 256, 1, 1, False, True, 1),         # direct kernel, same result
     (64, 64, 128, 2, 1, True, False, 1),         # stride-2 block end (explicit pad 1,1), direct
     (64, 64, 128, 2, 1, True, False, 0),         # stride-2, streaming (auto)
@@ -234,9 +231,6 @@ def _dw_ref(x, k, bias, stride, rate, pad, pre, post):
     (32, 32, 728, 1, 1, True, False, 2),         # streaming (register window) kernel
     (70, 40, 128, 1, 1, True, True, 2),          # streaming: several row strips, ragged columns
     (32, 32, 1536, 1, 2, False, True, 2),        # streaming, rate 2
-    (32, 32, 728, 1, 1, True, False, 4),         # flat streaming (default for stride 1)
-    (70, 40, 132, 1, 1, True, True, 4),          # flat: ragged rows, several strips, pieces not a multiple of 256
-    (32, 32, 1536, 1, 2, False, True, 4),        # flat, rate 2
 ])
 def test_dwconv_matches_conv2d(dev, h, w_, c, stride, rate, pre, post, direct):
     from asr_amd import ops
