@@ -87,6 +87,15 @@ __device__ __forceinline__ int asr_coord_to_int(float f) {
     return (f == f) ? (int)f : -1000000000;
 }
 
+// Split-f16 operand halves of an ACTIVATION: v ~= hi + lo, hi = f16(v), lo = f16(v - hi).  Saturating: |v| beyond f16's
+// largest finite value gives hi = +-65504 (and the remainder clamped likewise) instead of an infinity, so an out-of-range
+// activation degrades the result (finite, inexact) rather than poisoning everything downstream with inf / NaN.  In range
+// the clamps are the identity.  Supported range and what the host does about layers outside it: DESIGN.md 4.1.
+__device__ __forceinline__ void asr_split_f16(float v, _Float16& hi, _Float16& lo) {
+    hi = (_Float16)__builtin_fminf(__builtin_fmaxf(v, -65504.0f), 65504.0f);
+    lo = (_Float16)__builtin_fminf(__builtin_fmaxf(v - (float)hi, -65504.0f), 65504.0f);
+}
+
 // wave64 sum via DPP-free shuffles.
 __device__ __forceinline__ float asr_wave_sum(float v) {
 #pragma unroll

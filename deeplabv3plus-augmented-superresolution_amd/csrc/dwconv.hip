@@ -235,9 +235,10 @@ __global__ __launch_bounds__(256) void dw_stream_full_kernel(DwArgs p, int tiles
                 f16x4 hi, lo;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const _Float16 h = (_Float16)acc[e];
+                    _Float16 h, l;
+                    asr_split_f16(acc[e], h, l);
                     hi[e] = h;
-                    lo[e] = (_Float16)(acc[e] - (float)h);
+                    lo[e] = l;
                 }
                 // Lane pairs (channel quads 2j, 2j+1; c % 8 == 0) trade halves through DPP so that each lane issues ONE
                 // 16-byte store -- the even lane the 8 hi halfs of both quads, the odd lane their 8 lo halfs -- instead of
@@ -344,9 +345,10 @@ __global__ __launch_bounds__(ATHREADS) void aspp_dw3_kernel(AsppArgs p) {
                 f16x4 hi, lo;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const _Float16 h = (_Float16)acc[e];
+                    _Float16 h, l;
+                    asr_split_f16(acc[e], h, l);
                     hi[e] = h;
-                    lo[e] = (_Float16)(acc[e] - (float)h);
+                    lo[e] = l;
                 }
                 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
                 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));

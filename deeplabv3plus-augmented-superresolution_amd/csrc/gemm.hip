@@ -353,9 +353,10 @@ __device__ __forceinline__ void split_f16x8(const f32x4& a, const f32x4& b, f16x
     const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        const _Float16 h = (_Float16)v[j];
+        _Float16 h, l;
+        asr_split_f16(v[j], h, l);
         hi[j] = h;
-        lo[j] = (_Float16)(v[j] - (float)h);
+        lo[j] = l;
     }
 }
 

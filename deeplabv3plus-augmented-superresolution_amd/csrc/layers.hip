@@ -177,9 +177,10 @@ __global__ __launch_bounds__(256) void conv3x3_stem_mfma_kernel(const float* __r
         f16x8 ah[2], al[2];
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
-            const _Float16 hi = (_Float16)a[k];
+            _Float16 hi, lo;
+            asr_split_f16(a[k], hi, lo);
             ah[k >> 3][k & 7] = hi;
-            al[k >> 3][k & 7] = (_Float16)(a[k] - (float)hi);
+            al[k >> 3][k & 7] = lo;
         }
         f32x16 acc;
 #pragma unroll
@@ -296,9 +297,10 @@ __global__ __launch_bounds__(512) void entry_stem_fused_kernel(const float* __re
         f16x8 xh[2], xl[2];
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
-            const _Float16 hi = (_Float16)r.a[k];
+            _Float16 hi, lo;
+            asr_split_f16(r.a[k], hi, lo);
             xh[k >> 3][k & 7] = hi;
-            xl[k >> 3][k & 7] = (_Float16)(r.a[k] - (float)hi);
+            xl[k >> 3][k & 7] = lo;
         }
         f32x16 acc;
 #pragma unroll
@@ -318,9 +320,10 @@ __global__ __launch_bounds__(512) void entry_stem_fused_kernel(const float* __re
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const float v = r.in_map ? fmaxf(acc[4 * g4 + i] + b1v[4 * g4 + i], 0.0f) : 0.0f;
-                    const _Float16 h = (_Float16)v;
+                    _Float16 h, l;
+                    asr_split_f16(v, h, l);
                     hi[i] = h;
-                    lo[i] = (_Float16)(v - (float)h);
+                    lo[i] = l;
                 }
                 *reinterpret_cast<f16x4*>(line + ((g4 ^ swz) << 4) + hh * 8) = hi;
                 *reinterpret_cast<f16x4*>(line + (((4 + g4) ^ swz) << 4) + hh * 8) = lo;

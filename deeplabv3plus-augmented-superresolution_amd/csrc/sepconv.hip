@@ -131,9 +131,10 @@ __global__ __launch_bounds__(512) void sepconv_fused_kernel(const float* __restr
                 f16x4 hi, lo;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const _Float16 hf = (_Float16)acc[i];
+                    _Float16 hf, lf;
+                    asr_split_f16(acc[i], hf, lf);
                     hi[i] = hf;
-                    lo[i] = (_Float16)(acc[i] - (float)hf);
+                    lo[i] = lf;
                 }
                 if (lane16 >= 1 && lane16 <= SF_TW) {          // lanes 0 and 15 are the halo columns
                     const int line = (ry0 + r - 2) * SF_TW + lane16 - 1;

@@ -25,6 +25,14 @@ from . import _lib, ops, weights as W
 
 f32 = torch.float32
 
+# Range of the split-f16 GEMM operands (hi = f16(v), lo = f16(v - hi)): above 2^15 the f16 halves are a factor 2 from
+# overflow (the kernels saturate at 65504 instead of producing infinities, but the result is then inexact); a tensor whose
+# LARGEST magnitude is below 2^-12 keeps fewer than 13 of its 22 bits (lo falls under f16's subnormal spacing 2^-24).
+SPLIT_MAX = 2.0 ** 15
+SPLIT_W_MIN = 2.0 ** -12
+SPLIT_ACT_MIN = 2.0 ** -10
+SPLIT_HEADROOM = 2.0          # calibration routes a layer whose probe maximum is within this factor of SPLIT_MAX
+
 
 class _Buf:
     """NHWC activation: logical shape (b,h,w,c) stored with a pixel stride ``ld`` >= c that is a
@@ -45,8 +53,9 @@ class _Buf:
 class _Pool:
     """Exact-size free list: the net repeats a handful of activation sizes."""
 
-    def __init__(self, device):
+    def __init__(self, device, zero_fill=False):
         self.device = device
+        self.zero_fill = zero_fill          # range calibration: unwritten lanes must read as 0, not as garbage
         self.free = {}
         self.total_bytes = 0
         self.owned = []          # every tensor ever handed out: the plan stores raw pointers, so the pool
@@ -59,6 +68,8 @@ class _Pool:
         self.total_bytes += 4 * numel
         if os.environ.get("ASR_POISON"):            # debugging aid: fill fresh buffers with a sentinel value
             t = torch.full((numel,), float(os.environ["ASR_POISON"]), dtype=f32, device=self.device)
+        elif self.zero_fill:
+            t = torch.zeros(numel, dtype=f32, device=self.device)
         else:
             t = torch.empty(numel, dtype=f32, device=self.device)
         self.owned.append(t)
@@ -123,6 +134,8 @@ class DeeplabEngine:
         self.logits_name = "logits_semantic" if "logits_semantic/kernel" in weights else "custom_logits_semantic"
         self.p = {}
         self._plans = {}
+        self.routed_f32 = {}          # conv layer name -> reason: layers taken off the split-f16 kernels (range guard)
+        self._host_weights = weights  # kept by reference: a routed layer is re-packed for the exact-f32 kernel
         self._upload(weights)
 
     # -- parameters -----------------------------------------------------------------------------
@@ -130,12 +143,22 @@ class DeeplabEngine:
         return torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32)).to(self.device)
 
     def _put_conv(self, name, bn, eps, pack=True):
+        self._conv_meta = getattr(self, "_conv_meta", {})
+        self._conv_meta[name] = (bn, eps, pack)
         k, b = (W.fold_conv_bn(self._w, name, bn, eps) if bn else
                 (self._w[name + "/kernel"].reshape(-1, self._w[name + "/kernel"].shape[-1]).astype(np.float32),
                  self._w.get(name + "/bias")))
         kd = self._dev(k)
         conv = name == "entry_flow_conv1_2"                       # the one dense 3x3 on the matrix path (implicit GEMM)
         split = pack and self.precision == "f16x3" and (k.shape[1] > 64 or conv)
+        if split and name not in self.routed_f32:
+            # range guard of the split-f16 arithmetic, weight side (hi = f16(w) must be finite and carry bits): a folded
+            # kernel outside [2^-12, 2^15) in magnitude goes to the exact-f32 MFMA kernel
+            wmax = float(np.abs(k).max())
+            if not (SPLIT_W_MIN <= wmax < SPLIT_MAX):
+                self.routed_f32[name] = f"max |w| = {wmax:.3g} outside [{SPLIT_W_MIN:.3g}, {SPLIT_MAX:.3g})"
+        if name in self.routed_f32:
+            split = False
         wdev = (ops.pack_pw_weights_f16x3(kd) if split else ops.pack_pw_weights(kd)) if pack else kd
         fn = ("asr_conv3x3_mfma_f16x3" if split else "asr_conv3x3_mfma_f32") if conv else \
              ("asr_pwconv_mfma_f16x3" if split else "asr_pwconv_mfma_f32")
@@ -210,8 +233,8 @@ class DeeplabEngine:
         self.p[self.logits_name]["b"][class_id] += float(delta)
 
     # -- plan construction ----------------------------------------------------------------------
-    def _build_plan(self, B, H, Wd):
-        pool = _Pool(self.device)
+    def _build_plan(self, B, H, Wd, zero_fill=False):
+        pool = _Pool(self.device, zero_fill)
         steps = []          # (name, args, kind, flops, bytes)
         live = []           # buffers to release after a given step index
 
@@ -393,10 +416,10 @@ class DeeplabEngine:
             add("asr_conv3x3_stem_f16x3" if self.precision == "f16x3" else "asr_conv3x3_direct_f32",
                 (x_in.ptr, p1["w"].data_ptr(), p1["b"].data_ptr(), a1.ptr, B, H, Wd, 3, 32, 2, pt, pl,
                  h1, w1, 3, 32, 1), "conv", 2.0 * B * h1 * w1 * 27 * 32,
-                4.0 * (B * H * Wd * 3 + B * h1 * w1 * 32))
+                4.0 * (B * H * Wd * 3 + B * h1 * w1 * 32), label="entry_flow_conv1_1 stem", out=a1)
             add(p2["fn"], (a1.ptr, p2["w"].data_ptr(), p2["b"].data_ptr(), a2.ptr, B, h1, w1, 32, 64, 1, 1, 1, h1,
                            w1, 32, 64, 1), "conv", 2.0 * B * h1 * w1 * 288 * 64,
-                4.0 * (B * h1 * w1 * 96))
+                4.0 * (B * h1 * w1 * 96), label="entry_flow_conv1_2 conv3x3", out=a2)
             release(a1)
         x = block(a2, "entry_flow_block1", "conv", 2, 1, False)
         x, skip = block(x, "entry_flow_block2", "conv", 2, 1, False, return_skip=True)
@@ -437,7 +460,7 @@ class DeeplabEngine:
                 (x.ptr, p3["w"].data_ptr(), p3["b"].data_ptr(), ts[0].ptr, ts[1].ptr, ts[2].ptr, b, fh, fw, fc,
                  rates[0], rates[1], rates[2], x.ld, fc // 32 if split else ts[0].ld, 0, 1),
                 "dw", 3 * 18.0 * b * fh * fw * fc, 3 * 4.0 * 2 * b * fh * fw * fc,
-                label=f"aspp_dw3 {fh}x{fw}x{fc} r{rates[0]}/{rates[1]}/{rates[2]} fused" + (" split" if split else ""), out=ts[0])
+                label=f"aspp_dw3 {fh}x{fw}x{fc} r{rates[0]}/{rates[1]}/{rates[2]} fused" + (" split" if split else ""), out=ts)
             for i, t in enumerate(ts):
                 if split:
                     pp = self.p[f"aspp{i + 1}_pointwise"]
@@ -515,8 +538,69 @@ class DeeplabEngine:
             _lib.check(getattr(lib, name)(*args, s), name)
             if out is not None:
                 torch.cuda.synchronize()
-                cap.append((label, out.t.view(B, -1).clone()))
+                first = out[0] if isinstance(out, (list, tuple)) else out
+                cap.append((label, first.t.view(B, -1).clone()))
         return cap
+
+    # -- range guard of the split-f16 GEMMs -----------------------------------------------------------
+    SPLIT_GEMMS = ("asr_pwconv_mfma_f16x3", "asr_pwconv_mfma_f16x3_presplit", "asr_conv3x3_mfma_f16x3")
+    SPLIT_PRODUCERS = ("asr_dwconv3x3_nhwc_split_f16", "asr_aspp_dwconv3_nhwc_split_f16")
+
+    def calibrate_range(self, x_dev, verbose=True):
+        """Activation side of the range guard.  Runs forward passes of the probe batch ``x_dev`` [B,H,W,3] (B small) on a plan
+        with the in-kernel fusions opened up (repeated until no layer moves: at most 4 passes), reads the largest magnitude of every split-f16 GEMM's A operand, and moves
+        each layer whose operand is within SPLIT_HEADROOM of 2^15 (f16 overflow at 65504) or entirely below 2^-10 (fewer
+        than 13 significant bits left) to the exact-f32 MFMA kernel for the lifetime of the engine.  Returns
+        {layer: reason} of the layers moved by this call; the cumulative set is ``routed_f32``.  The kernels saturate
+        rather than overflow, so a later input that exceeds the probe's range gives finite, less exact results; call
+        this again with such an input to re-route.  No-op for precision='f32'."""
+        if self.precision != "f16x3":
+            return {}
+        moved_all = {}
+        for _pass in range(4):            # a saturated layer hides the true range of the layers behind it: repeat until stable
+            moved = self._calibrate_pass(x_dev, verbose)
+            if not moved:
+                break
+            moved_all.update(moved)
+        return moved_all
+
+    def _calibrate_pass(self, x_dev, verbose):
+        B, H, Wd, _ = x_dev.shape
+        saved = self.disabled
+        self.disabled = saved | {"fused_stem", "fused_sepconv"}      # their internal operands become visible tensors
+        try:
+            plan = self._build_plan(B, H, Wd, zero_fill=True)
+        finally:
+            self.disabled = saved
+        plan["x_in"].t.copy_(x_dev.reshape(-1))
+        lib = _lib.load()
+        s = _lib.stream_ptr()
+        maxima = {plan["x_in"].ptr: float(x_dev.abs().max())}
+        moved = {}
+        for (name, args, _k, _f, _b, label), out in zip(plan["steps"], plan["outs"]):
+            layer = label.split(" ")[0] if label else ""
+            if name in self.SPLIT_GEMMS and layer in self.p and layer not in self.routed_f32:
+                m = maxima.get(args[0])
+                if m is not None and (m != m or (m > 0.0 and (m * SPLIT_HEADROOM >= SPLIT_MAX or m < SPLIT_ACT_MIN))):
+                    moved[layer] = (f"max |activation| = {m:.3g} on the probe batch, outside "
+                                    f"[{SPLIT_ACT_MIN:.3g}, {SPLIT_MAX / SPLIT_HEADROOM:.3g})")
+            _lib.check(getattr(lib, name)(*args, s), name)
+            for buf in (out if isinstance(out, (list, tuple)) else ([out] if out is not None else [])):
+                t = buf.t.view(torch.float16) if name in self.SPLIT_PRODUCERS else buf.t
+                maxima[buf.ptr] = float(t.abs().max())               # (a saturated split half reads 65504: still caught)
+        if moved:
+            self.routed_f32.update(moved)
+            self._w = self._host_weights
+            for layer in moved:
+                self._put_conv(layer, *self._conv_meta[layer])
+            del self._w
+            torch.cuda.synchronize(self.device)
+            self._plans.clear()
+            if verbose:
+                import sys
+                for layer, why in moved.items():
+                    print(f"asr_amd: {layer} runs on the exact-f32 MFMA kernel ({why})", file=sys.stderr)
+        return moved
 
     def forward(self, x_dev, profile=None, lane=0):
         """x_dev: [B,H,W,3] float32 device tensor -> logits [B,H/4,W/4,classes] (a view of plan

@@ -79,7 +79,8 @@ class DeeplabV3Plus:
         return DeeplabModel(params, self.input_shape, self.classes, final_upsample, self.last_activation,
                             precision=self.precision, backbone=self.backbone, alpha=self.alpha, OS=self.OS,
                             reshape_outputs=self.reshape_outputs, decoder=decoder, first_upsample_size=first_upsample_size,
-                            class_prediction=final_class_prediction)
+                            class_prediction=final_class_prediction,
+                            calibrate=bool(self.load_weights and path))   # real weights: activation ranges are unknown
 
 
 class DeeplabModel:
@@ -88,7 +89,10 @@ class DeeplabModel:
 
     def __init__(self, params, input_shape, classes, final_upsample, last_activation, precision=None,
                  backbone="xception", alpha=1.0, OS=16, reshape_outputs=False, decoder="full",
-                 first_upsample_size=(128, 128), class_prediction=True):
+                 first_upsample_size=(128, 128), class_prediction=True, calibrate=False):
+        """calibrate: run DeeplabEngine.calibrate_range on the first two images of the first predict call (the range guard
+        of the split-f16 GEMMs; the default for weights loaded from a file, whose activation ranges nobody has seen)."""
+        self._calibrate_pending = bool(calibrate)
         self.input_shape = tuple(input_shape)
         self.reshape_outputs = reshape_outputs
         self.classes = classes
@@ -113,6 +117,9 @@ class DeeplabModel:
         n, h, w, c = x.shape
         if c != 3:
             raise ValueError(f"expected [N,H,W,3], got {tuple(x.shape)}")
+        if self._calibrate_pending:
+            self._calibrate_pending = False
+            self.calibrate_range(x[:min(2, n)])
         outs = []
         for i in range(0, n, batch_size):
             xb = x[i:i + batch_size].to(self.device, non_blocking=True).contiguous()
@@ -131,6 +138,14 @@ class DeeplabModel:
         if self.last_activation in ("softmax", "sigmoid"):
             out = ops.class_activation(out.contiguous(), self.last_activation)
         return out
+
+    def calibrate_range(self, x):
+        """Range guard of the split-f16 GEMMs on a probe batch x [B,H,W,3] (host array or device tensor): layers whose
+        operands leave the f16 split's range move to the exact-f32 kernels (DeeplabEngine.calibrate_range).  Returns
+        {layer: reason}."""
+        if not isinstance(x, torch.Tensor):
+            x = torch.as_tensor(np.ascontiguousarray(x, dtype=np.float32))
+        return self.engine.calibrate_range(x.to(self.device).contiguous())
 
     def _upsample(self, logits, hw):
         """Resizing(H, W, bilinear) of the logits (model.py:108-111); channels padded to a multiple

@@ -427,6 +427,18 @@ def aspp_dwconv3(x, w3, bias3, rates=(6, 12, 18), pre_relu=False, post_relu=True
     return outs
 
 
+def aspp_dwconv3_split(x, w3, bias3, rates=(6, 12, 18), pre_relu=False, post_relu=True):
+    """aspp_dwconv3 with its three outputs as split-f16 GEMM operands (c % 32 == 0): three buffers
+    [B*H*W, c / 32, 32] of float32-typed storage for pwconv_presplit."""
+    b, h, w, c = x.shape
+    if c % 32:
+        raise AsrError("aspp_dwconv3_split: channels must be a multiple of 32")
+    outs = [torch.empty((b * h * w, c // 32, 32), dtype=f32, device=x.device) for _ in range(3)]
+    call("asr_aspp_dwconv3_nhwc_split_f16", ptr(x), ptr(w3), ptr(bias3), ptr(outs[0]), ptr(outs[1]), ptr(outs[2]), b, h, w, c,
+         int(rates[0]), int(rates[1]), int(rates[2]), c, c // 32, int(pre_relu), int(post_relu), stream_ptr())
+    return outs
+
+
 def dwconv3x3(x, w_33c, bias, stride=1, rate=1, pad_top=None, pad_left=None, out_hw=None, pre_relu=False,
               post_relu=False, force_direct=0, out=None, ldy=None):
     """force_direct is the kernel mode: 0 auto, 1 direct, 2 streaming register window."""

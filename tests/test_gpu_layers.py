@@ -322,3 +322,77 @@ def test_presplit_sepconv_matches_the_f32_handoff(dev, c, n, hw, stride, rate):
     rec = (halves[:, :, 0, :] + halves[:, :, 1, :]).reshape(m, chunks * 32)
     np.testing.assert_allclose(rec[:, :c].cpu().numpy(), ref_dw.reshape(m, c).cpu().numpy(), rtol=3e-7, atol=1e-7)
     assert float(rec[:, c:].abs().max()) == 0.0 if chunks * 32 > c else True
+
+
+def test_aspp_split_operands_match_the_f32_outputs(dev):
+    """asr_aspp_dwconv3_nhwc_split_f16 at the product shape (32 x 32 x 2048, rates 6 / 12 / 18, model.py:212-221): the
+    split-f16 chunks it hands to the three pointwise GEMMs reproduce the f32 outputs of asr_aspp_dwconv3_nhwc_f32 to
+    2^-22, and the GEMM on them stays f32-grade against the float64 product."""
+    from asr_amd import ops
+    rng = np.random.default_rng(77)
+    b, hw, c, n = 2, 32, 2048, 256
+    x = ops.to_device(_rand(rng, b, hw, hw, c))
+    w3 = ops.to_device(_rand(rng, 3, 3, 3, c, scale=0.3))
+    b3 = ops.to_device(_rand(rng, 3, c, scale=0.1))
+    ref = ops.aspp_dwconv3(x, w3, b3, rates=(6, 12, 18), pre_relu=False, post_relu=True)
+    got = ops.aspp_dwconv3_split(x, w3, b3, rates=(6, 12, 18), pre_relu=False, post_relu=True)
+    wk_h = _rand(rng, c, n, scale=(1.0 / c) ** 0.5)
+    w16 = ops.pack_pw_weights_f16x3(ops.to_device(wk_h))
+    bk_h = _rand(rng, n, scale=0.1)
+    for r, g in zip(ref, got):
+        m = b * hw * hw
+        halves = g.view(torch.float16).reshape(m, c // 32, 2, 32).float()
+        rec = (halves[:, :, 0, :] + halves[:, :, 1, :]).reshape(m, c)
+        np.testing.assert_allclose(rec.cpu().numpy(), r.reshape(m, c).cpu().numpy(), rtol=3e-7, atol=1e-7)
+        out = ops.pwconv_presplit(g, w16, ops.to_device(bk_h), c, n, c // 32, relu=1).cpu().numpy()
+        a64 = r.reshape(m, c).cpu().numpy().astype(np.float64)
+        exact = np.maximum(a64 @ wk_h.astype(np.float64) + bk_h, 0)
+        bound = np.abs(a64) @ np.abs(wk_h).astype(np.float64) + np.abs(bk_h)
+        assert (np.abs(out - exact) / bound).max() <= 4e-6
+
+
+def test_split_f16_operands_saturate_and_document_their_range(dev):
+    """Range behaviour of the split-f16 operands (hi = f16(v), lo = f16(v - hi)), both producers (the in-kernel split of
+    asr_pwconv_mfma_f16x3 and the depthwise hand-off of asr_dwconv3x3_nhwc_split_f16):
+      * |v| up to ~5e4: f32-grade (the 4e-6 * sum |x||w| bound);
+      * |v| beyond f16's 65504 (here up to 3e5): the halves saturate -- every output stays FINITE, rows that hold no
+        out-of-range value keep the f32-grade bound, the others are inexact (the engine's calibrate_range moves such a
+        layer to the exact-f32 kernel, test_gpu_model.py::test_range_guard_routes_layers_to_the_exact_f32_kernels);
+      * tiny operands (|v| ~ 1e-8): the absolute error is bounded by f16's subnormal spacing, 2^-24 * sum |w|."""
+    from asr_amd import ops
+    rng = np.random.default_rng(5)
+    m, k, n = 512, 256, 256
+    wk_h = _rand(rng, k, n, scale=(1.0 / k) ** 0.5)
+    wk = ops.to_device(wk_h)
+    w16 = ops.pack_pw_weights_f16x3(wk)
+    w64 = wk_h.astype(np.float64)
+
+    def both_paths(x_h):
+        """x_h [m, k] -> outputs of the in-kernel split GEMM and of the depthwise (identity tap) hand-off + LDS-DMA GEMM"""
+        xd = ops.to_device(x_h)
+        a = ops.pwconv(xd, w16, None, k, n, f16x3=True).cpu().numpy()
+        wd = torch.zeros(3, 3, k, device=xd.device)
+        wd[1, 1] = 1.0
+        xs, _, chunks = ops.dwconv3x3_split(xd.reshape(2, 16, 16, k), wd, torch.zeros(k, device=xd.device))
+        b = ops.pwconv_presplit(xs, w16, None, k, n, chunks).cpu().numpy()
+        return a, b
+
+    # in range: row scales over four orders of magnitude, the largest values just below f16's 65504
+    x = (np.clip(_rand(rng, m, k), -4.5, 4.5) * np.exp(rng.uniform(np.log(1.0), np.log(1.2e4), (m, 1)))).astype(np.float32)
+    assert 3e4 < np.abs(x).max() < 6e4
+    bound = np.abs(x).astype(np.float64) @ np.abs(w64)
+    for out in both_paths(x):
+        assert (np.abs(out - x.astype(np.float64) @ w64) / bound).max() <= 4e-6
+    # out of range in rows 0..63 only
+    x2 = x.copy()
+    x2[:64, ::7] = (rng.choice([-1.0, 1.0], (64, x2[:, ::7].shape[1])) * rng.uniform(7e4, 3e5, (64, x2[:, ::7].shape[1]))).astype(np.float32)
+    bound2 = np.abs(x2).astype(np.float64) @ np.abs(w64)
+    for out in both_paths(x2):
+        assert np.isfinite(out).all()
+        assert (np.abs(out[64:] - x2[64:].astype(np.float64) @ w64) / bound2[64:]).max() <= 4e-6
+        assert (np.abs(out[:64] - x2[:64].astype(np.float64) @ w64) / bound2[:64]).max() <= 1.0     # saturated, not garbage
+    # tiny operands
+    x3 = (_rand(rng, m, k) * 1e-8).astype(np.float32)
+    abs_bound = 2.0 ** -24 * np.abs(w64).sum(axis=0)
+    for out in both_paths(x3):
+        assert (np.abs(out - x3.astype(np.float64) @ w64) <= abs_bound[None, :] + 1e-12).all()

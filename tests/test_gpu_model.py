@@ -215,3 +215,37 @@ def test_pipelined_submit_equals_sequential(dev, synthetic):
         for k in ("standard", "aug", "max", "mean"):
             assert torch.equal(r[k], g[k]), k
         np.testing.assert_array_equal(r["ious"], g["ious"])
+
+
+@pytest.mark.parametrize("case", ["large-activations", "tiny-activations", "large-weights"])
+def test_range_guard_routes_layers_to_the_exact_f32_kernels(dev, synthetic, case):
+    """The split-f16 GEMMs cover operands in [2^-10, 2^15); outside it the engine moves the layer to asr_pwconv_mfma_f32:
+    weights at upload (folded kernel out of range), activations by calibrate_range on a probe batch.  The logits then
+    match the oracle as closely as everywhere else; without calibration an overflowing activation still gives finite
+    logits (the kernels saturate)."""
+    from asr_amd.model import DeeplabModel
+    w = dict(synthetic)
+    if case == "large-activations":       # everything after the stem is 3e4 times larger: up to ~1e5 inside the net
+        w["entry_flow_conv1_1_BN/gamma"] = w["entry_flow_conv1_1_BN/gamma"] * np.float32(3e4)
+        w["entry_flow_conv1_1_BN/beta"] = w["entry_flow_conv1_1_BN/beta"] * np.float32(3e4)
+    elif case == "tiny-activations":
+        w["entry_flow_conv1_1_BN/gamma"] = w["entry_flow_conv1_1_BN/gamma"] * np.float32(1e-6)
+        w["entry_flow_conv1_1_BN/beta"] = w["entry_flow_conv1_1_BN/beta"] * np.float32(1e-6)
+    else:                                 # one folded kernel beyond f16: routed at upload, before any data is seen
+        w["aspp0/kernel"] = w["aspp0/kernel"] * np.float32(1e6)
+    rng = np.random.default_rng(41)
+    x = rng.random((2, 64, 64, 3), dtype=np.float32)
+    ref = OracleDeeplabV3Plus(w).predict(x, batch_size=2)
+    model = DeeplabModel(w, (64, 64, 3), 21, False, None, precision="f16x3")
+    if case == "large-weights":
+        assert "aspp0" in model.engine.routed_f32
+    raw = model.predict(x, batch_size=2)
+    assert np.isfinite(raw).all()
+    moved = model.calibrate_range(x)
+    if case == "large-activations":
+        assert len(moved) >= 10 and "middle_flow_unit_8_separable_conv2_pointwise" in moved
+    elif case == "tiny-activations":     # the next BatchNorm's beta brings the scale back: only the stem's second conv sees it
+        assert "entry_flow_conv1_2" in moved
+    got = model.predict(x, batch_size=2)
+    np.testing.assert_allclose(got, ref, rtol=0, atol=2e-4 * np.abs(ref).max())
+    assert model.calibrate_range(x) == {}                       # idempotent: nothing left to move
