@@ -73,6 +73,9 @@ SIGNATURES = {
     "asr_opm_slice_f32": (_i, [_vp, _vp, _vp, _i, _i64, _i, _i, _fl, _fl, _vp]),
     "asr_threshold_f32": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _fl, _i, _vp]),
     "asr_iou_counts_i32": (_i, [_vp, _vp, _vp, _i64, _i, _i, _i, _vp]),
+    "asr_iou_counts_shared_truth_i32": (_i, [_vp, _vp, _vp, _i64, _i, _i, _i, _vp]),
+    "asr_minmax_normalize_f32": (_i, [_vp, _vp, _vp, _i64, _i, _fl, _fl, _vp]),
+    "asr_standard_mask_i32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "asr_class_counts_i32": (_i, [_vp, _vp, _vp, _i64, _i, _vp]),
     "asr_pwconv_packed_floats": (_sz, [_i, _i]),
     "asr_pwconv_pack_weights_f32": (_i, [_vp, _vp, _i, _i, _vp]),

@@ -436,6 +436,34 @@ __global__ __launch_bounds__(256) void resize_bilinear_kernel(const float* __res
     *reinterpret_cast<f32x4*>(y + ((b * h_out + oy) * w_out + ox) * ldy + c4 * 4) = top + (bot - top) * ty;
 }
 
+// Standard-output mask (generate_standard_output.py:52-65 with the model's final Resizing, model.py:108-111): bilinear
+// upsample of one logits map (half-pixel, the arithmetic of resize_bilinear_kernel), argmax over the classes (first
+// maximum), keep class_id else 0 -- one pass, the upsampled logits never exist.
+__global__ __launch_bounds__(256) void standard_mask_kernel(const float* __restrict__ logits, int* __restrict__ out, int h_in,
+                                                            int w_in, int classes, int h_out, int w_out, float scale_y,
+                                                            float scale_x, int class_id) {
+    const int ox = blockIdx.x * 256 + threadIdx.x, oy = blockIdx.y;
+    if (ox >= w_out) return;
+    const float py = ((float)oy + 0.5f) * scale_y - 0.5f, px = ((float)ox + 0.5f) * scale_x - 0.5f;
+    const float fy = floorf(py), fx = floorf(px);
+    const int ylo = max((int)fy, 0), yhi = min((int)ceilf(py), h_in - 1);
+    const int xlo = max((int)fx, 0), xhi = min((int)ceilf(px), w_in - 1);
+    const float ty = py - fy, tx = px - fx;
+    const float* tl = logits + ((long long)ylo * w_in + xlo) * classes;
+    const float* tr = logits + ((long long)ylo * w_in + xhi) * classes;
+    const float* bl = logits + ((long long)yhi * w_in + xlo) * classes;
+    const float* br = logits + ((long long)yhi * w_in + xhi) * classes;
+    float best = 0.0f;
+    int arg = 0;
+    for (int c = 0; c < classes; ++c) {
+        const float top = tl[c] + (tr[c] - tl[c]) * tx;
+        const float bot = bl[c] + (br[c] - bl[c]) * tx;
+        const float v = top + (bot - top) * ty;
+        if (c == 0 || v > best) { best = v; arg = c; }
+    }
+    out[(long long)oy * w_out + ox] = (arg == class_id) ? class_id : 0;
+}
+
 int cap_grid(long long total) {
     const long long g = asr_cdiv(total, 256);
     return (int)(g < 8192 ? (g > 0 ? g : 1) : 8192);
@@ -528,6 +556,19 @@ extern "C" int asr_resize_bilinear_f32(const float* x, float* y, int batch, int 
     ASR_UNSUPPORTED(batch > 65535 || h_out > 65535, "asr_resize_bilinear_f32: batch and h_out must not exceed 65535 (grid dimensions)");
     hipLaunchKernelGGL(resize_bilinear_kernel, dim3((unsigned)asr_cdiv((long long)w_out * (c >> 2), 256), (unsigned)h_out, (unsigned)batch),
                        dim3(256), 0, asr_stream(stream), x, y, batch, h_in, w_in, c, h_out, w_out, ldx, ldy, sy, sx);
+    ASR_LAUNCH_CHECK();
+    return ASR_OK;
+}
+
+extern "C" int asr_standard_mask_i32(const float* logits, int32_t* mask, int h_in, int w_in, int classes, int h_out, int w_out,
+                                     int class_id, asr_stream_t stream) {
+    ASR_REQUIRE(logits && mask, "asr_standard_mask_i32: null pointer");
+    ASR_REQUIRE(h_in > 0 && w_in > 0 && classes > 0 && h_out > 0 && w_out > 0 && h_out <= 65535 && class_id >= 0 &&
+                    class_id < classes,
+                "asr_standard_mask_i32: bad shape / class");
+    const float sy = (float)h_in / (float)h_out, sx = (float)w_in / (float)w_out;
+    hipLaunchKernelGGL(standard_mask_kernel, dim3((unsigned)asr_cdiv(w_out, 256), (unsigned)h_out), dim3(256), 0, asr_stream(stream),
+                       logits, mask, h_in, w_in, classes, h_out, w_out, sy, sx, class_id);
     ASR_LAUNCH_CHECK();
     return ASR_OK;
 }

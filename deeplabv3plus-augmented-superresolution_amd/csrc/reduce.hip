@@ -144,6 +144,20 @@ __global__ __launch_bounds__(256) void opm_slice_kernel(const float* __restrict_
     }
 }
 
+// ---- min_max_normalization of a stack with its own global minimum / maximum (load_SR_data, superres_utils.py:183-206) ----
+__global__ __launch_bounds__(256) void minmax_normalize_kernel(const float* __restrict__ x, float* __restrict__ out,
+                                                               const float* __restrict__ seg_minmax, int64_t per_seg,
+                                                               float new_min, float new_max) {
+    const int seg = blockIdx.y;
+    const float mn = seg_minmax[seg * 2 + 0], mxv = seg_minmax[seg * 2 + 1];
+    const float den = ((mxv - mn) != 0.0f) ? (mxv - mn) : 1.0f;
+    const float span = new_max - new_min;
+    const float* p = x + (int64_t)seg * per_seg;
+    float* o = out + (int64_t)seg * per_seg;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < per_seg; i += (int64_t)gridDim.x * 256)
+        o[i] = new_min + ((p[i] - mn) * span) / den;
+}
+
 // ---- threshold_image -----------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void threshold_kernel(const float* __restrict__ img, const float* __restrict__ th_mask,
                                                         const float* __restrict__ seg_minmax, int32_t* __restrict__ out,
@@ -165,9 +179,9 @@ __global__ __launch_bounds__(256) void threshold_kernel(const float* __restrict_
 // ---- IoU counts: counts[seg] = {inter_c, union_c, inter_bg, union_bg} ------------------------------
 __global__ __launch_bounds__(256) void iou_counts_kernel(const int32_t* __restrict__ truth, const int32_t* __restrict__ pred,
                                                          unsigned long long* __restrict__ counts, int64_t per_seg,
-                                                         int class_id, int include_bg) {
+                                                         int64_t truth_stride, int class_id, int include_bg) {
     const int seg = blockIdx.y;
-    const int32_t* t = truth + (int64_t)seg * per_seg;
+    const int32_t* t = truth + (int64_t)seg * truth_stride;          // truth_stride 0: every segment against one label map
     const int32_t* q = pred + (int64_t)seg * per_seg;
     unsigned int ic = 0, uc = 0, ib = 0, ub = 0;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < per_seg; i += (int64_t)gridDim.x * 256) {
@@ -326,15 +340,38 @@ extern "C" int asr_threshold_f32(const float* image, const float* th_mask, float
     return ASR_OK;
 }
 
-extern "C" int asr_iou_counts_i32(const int32_t* truth, const int32_t* pred, int64_t* counts, int64_t per_segment,
-                                  int segments, int class_id, int include_bg, asr_stream_t stream) {
-    ASR_REQUIRE(truth && pred && counts, "asr_iou_counts_i32: null pointer");
-    ASR_REQUIRE(per_segment > 0 && segments > 0 && segments <= 65535, "asr_iou_counts_i32: bad shape");
+static int iou_counts_common(const char* fn, const int32_t* truth, const int32_t* pred, int64_t* counts, int64_t per_segment,
+                             int64_t truth_stride, int segments, int class_id, int include_bg, asr_stream_t stream) {
+    ASR_REQUIRE(truth && pred && counts, "%s: null pointer", fn);
+    ASR_REQUIRE(per_segment > 0 && segments > 0 && segments <= 65535, "%s: bad shape", fn);
     hipStream_t s = asr_stream(stream);
     ASR_HIP_CHECK(hipMemsetAsync(counts, 0, sizeof(int64_t) * 4 * segments, s));
     hipLaunchKernelGGL(iou_counts_kernel, dim3(stream_grid(per_segment) > 64 ? 64 : stream_grid(per_segment), segments),
-                       dim3(256), 0, s, truth, pred, reinterpret_cast<unsigned long long*>(counts), per_segment, class_id,
-                       include_bg);
+                       dim3(256), 0, s, truth, pred, reinterpret_cast<unsigned long long*>(counts), per_segment, truth_stride,
+                       class_id, include_bg);
+    ASR_LAUNCH_CHECK();
+    return ASR_OK;
+}
+
+extern "C" int asr_iou_counts_i32(const int32_t* truth, const int32_t* pred, int64_t* counts, int64_t per_segment,
+                                  int segments, int class_id, int include_bg, asr_stream_t stream) {
+    return iou_counts_common("asr_iou_counts_i32", truth, pred, counts, per_segment, per_segment, segments, class_id, include_bg,
+                             stream);
+}
+
+extern "C" int asr_iou_counts_shared_truth_i32(const int32_t* truth, const int32_t* preds, int64_t* counts, int64_t pixels,
+                                               int num_preds, int class_id, int include_bg, asr_stream_t stream) {
+    return iou_counts_common("asr_iou_counts_shared_truth_i32", truth, preds, counts, pixels, 0, num_preds, class_id,
+                             include_bg, stream);
+}
+
+extern "C" int asr_minmax_normalize_f32(const float* x, float* out, float* minmax_ws, int64_t per_segment, int segments,
+                                        float new_min, float new_max, asr_stream_t stream) {
+    ASR_REQUIRE(x && out && minmax_ws, "asr_minmax_normalize_f32: null pointer");
+    int rc = asr_minmax_f32(x, minmax_ws, per_segment, segments, stream);
+    if (rc != ASR_OK) return rc;
+    hipLaunchKernelGGL(minmax_normalize_kernel, dim3(stream_grid(per_segment), segments), dim3(256), 0, asr_stream(stream), x, out,
+                       minmax_ws, per_segment, new_min, new_max);
     ASR_LAUNCH_CHECK();
     return ASR_OK;
 }

@@ -249,6 +249,28 @@ def minmax(x, segments=1):
     return out
 
 
+def minmax_normalize(x, segments=1, new_min=0.0, new_max=1.0):
+    """min_max_normalization of each of ``segments`` equal parts of x with its own global extrema (device, one call)."""
+    per = x.numel() // segments
+    if per * segments != x.numel() or per == 0:
+        raise AsrError("minmax_normalize: tensor does not split into equal non-empty segments")
+    out = torch.empty_like(x)
+    ws = torch.empty((segments, 2), dtype=f32, device=x.device)
+    call("asr_minmax_normalize_f32", ptr(x), ptr(out), ptr(ws), per, segments, float(new_min), float(new_max), stream_ptr())
+    return out
+
+
+def standard_mask(logits0, out_hw, class_id, out=None):
+    """logits0 [h,w,C] of the un-augmented image -> int32 mask [H,W] in {0, class_id}: bilinear upsample + argmax + class
+    filter in one kernel (generate_standard_output.py:52-65)."""
+    h, w, c = logits0.shape
+    if out is None:
+        out = torch.empty(tuple(out_hw), dtype=torch.int32, device=logits0.device)
+    call("asr_standard_mask_i32", ptr(logits0), ptr(out, torch.int32), h, w, c, int(out_hw[0]), int(out_hw[1]), int(class_id),
+         stream_ptr())
+    return out
+
+
 def class_activation(logits, kind):
     """softmax / sigmoid over the last (class) axis, in a new tensor."""
     classes = logits.shape[-1]
@@ -295,15 +317,30 @@ def opm_slice(logits, class_id, new_min=0.0, new_max=1.0):
     return out
 
 
-def threshold(image, th_value, th_factor=0.15, th_mask=None, segments=1):
+def threshold(image, th_value, th_factor=0.15, th_mask=None, segments=1, out=None):
     per = image.numel() // segments
-    out = torch.empty(image.shape, dtype=torch.int32, device=image.device)
+    if out is None:
+        out = torch.empty(image.shape, dtype=torch.int32, device=image.device)
+    elif out.numel() != image.numel():
+        raise AsrError("threshold: out size mismatch")
     ws = torch.empty((segments, 2), dtype=f32, device=image.device)
     if th_mask is not None and th_mask.shape != image.shape:
         raise AsrError("threshold: th_mask shape mismatch")
     call("asr_threshold_f32", ptr(image), ptr(th_mask, allow_none=True), ptr(ws), ptr(out, torch.int32), per, segments,
          float(np.float32(th_factor)), int(th_value), stream_ptr())
     return out
+
+
+def iou_counts_shared_truth(truth, preds, class_id, include_bg=False):
+    """preds [K, ...] int32 masks against ONE int32 label map of the same pixel count -> int64 [K, 4]."""
+    k = preds.shape[0]
+    per = preds.numel() // k
+    if truth.numel() != per:
+        raise AsrError("iou_counts_shared_truth: size mismatch")
+    counts = torch.empty((k, 4), dtype=torch.int64, device=truth.device)
+    call("asr_iou_counts_shared_truth_i32", ptr(truth, torch.int32), ptr(preds, torch.int32), ptr(counts, torch.int64), per, k,
+         int(class_id), int(bool(include_bg)), stream_ptr())
+    return counts
 
 
 def iou_counts(truth, pred, class_id, include_bg=False, segments=1):

@@ -28,21 +28,17 @@ class HotPath:
         self._side = None
         self._lanes = {}
 
-    def _threshold(self, target, target_max):
+    def _threshold(self, target, target_max, out=None):
         if target_max is not None:
-            return ops.threshold(target, self.class_id, th_mask=target_max)
-        return ops.threshold(target, self.class_id, th_factor=self.th_factor)
+            return ops.threshold(target, self.class_id, th_mask=target_max, out=out)
+        return ops.threshold(target, self.class_id, th_factor=self.th_factor, out=out)
 
-    def standard_mask(self, logits0, out_hw):
+    MASK_KEYS = ("standard", "aug", "max", "mean")          # rows of the per-image mask buffer
+
+    def standard_mask(self, logits0, out_hw, out=None):
         """generate_standard_output.py:52-65: final bilinear upsample + argmax + class filter, from the
-        logits of the un-augmented copy 0."""
-        h, w, c = logits0.shape
-        cp = (c + 3) // 4 * 4
-        padded = torch.full((1, h, w, cp), -3.0e38, dtype=torch.float32, device=logits0.device)
-        padded[0, :, :, :c] = logits0
-        up = ops.resize_bilinear(padded, out_hw)
-        am = ops.argmax(up)[0]
-        return torch.where(am == self.class_id, am, torch.zeros_like(am))
+        logits of the un-augmented copy 0 (one kernel)."""
+        return ops.standard_mask(logits0.contiguous(), out_hw, self.class_id, out=out)
 
     # ---- stage 1 (model stream): augment -> forward -> OPM (-> standard mask) --------------------------
     def _stage_model(self, image_dev, angles, shifts, profile=None, want_standard=True, lane=0):
@@ -51,9 +47,10 @@ class HotPath:
         preds = self.model.predict_device(copies, batch_size=self.batch_size, profile=profile, lane=lane)
         del copies
         cls, mx = au.output_processing(preds, self.class_id, self.mode)
-        res = {}
+        # the image's masks live in one [4, H, W] int32 buffer (rows MASK_KEYS): the IoU kernel reads it as it stands
+        res = {"_masks": torch.empty((len(self.MASK_KEYS),) + tuple(out_hw), dtype=torch.int32, device=preds.device)}
         if want_standard:
-            res["standard"] = self.standard_mask(preds[0], out_hw)
+            res["standard"] = self.standard_mask(preds[0], out_hw, out=res["_masks"][0])
         del preds
         y = cls[None]
         ymax = mx[None] if mx is not None else None
@@ -82,7 +79,8 @@ class HotPath:
             else:
                 tgt = sr.realign_batch(y, a, s, t)
                 tmax = sr.realign_batch(ymax, a, s, t) if ymax is not None else None
-            res[t] = self._threshold(tgt[0], tmax[0] if tmax is not None else None)
+            res[t] = self._threshold(tgt[0], tmax[0] if tmax is not None else None,
+                                     out=res["_masks"][self.MASK_KEYS.index(t)])
         if gt_dev is not None:
             res["_iou_keys"], res["_iou_counts"] = self._iou_counts(res, gt_dev)
         return res
@@ -136,24 +134,26 @@ class HotPath:
         return _Pending(self, res, done, keep=(y, ymax, gt_dev, image_dev))
 
     def _finish(self, res):
+        res.pop("_masks", None)          # the rows stay alive through the per-key views
         if "_iou_counts" in res:
             res["ious"] = self._ious_from_counts(res.pop("_iou_keys"), res.pop("_iou_counts").cpu().numpy())
         return res
 
     @staticmethod
     def _normalise(stack):
-        mm = ops.minmax(stack.contiguous())[0]
-        den = mm[1] - mm[0]
-        den = torch.where(den != 0, den, torch.ones_like(den))
-        return ((stack - mm[0]) / den).contiguous()
+        """load_SR_data's global min-max normalisation of an image's masks to [0, 1] (superres_utils.py:183-206)."""
+        return ops.minmax_normalize(stack.contiguous(), segments=1, new_min=0.0, new_max=1.0)
 
     def _iou_counts(self, res, gt_dev):
-        """Integer intersection / union counts of every produced mask against the ground truth (device)."""
-        gt = gt_dev.reshape(-1).to(torch.int32)
-        keys = [k for k in ("standard", "aug", "max", "mean") if k in res]
-        preds = torch.stack([res[k].reshape(-1).to(torch.int32) for k in keys])
-        truth = gt[None].expand(len(keys), -1).contiguous()
-        return keys, ops.iou_counts(truth, preds, self.class_id, include_bg=True, segments=len(keys))
+        """Integer intersection / union counts of every produced mask against the ground truth (device): one launch over
+        the image's mask buffer; rows of masks that were not asked for are ignored."""
+        keys = [k for k in self.MASK_KEYS if k in res]
+        rows = [self.MASK_KEYS.index(k) for k in keys]
+        masks = res["_masks"]
+        if rows != list(range(len(self.MASK_KEYS))):                    # a subset of the four masks: compact it
+            masks = masks[rows].contiguous()
+        gt = gt_dev if gt_dev.dtype == torch.int32 else gt_dev.to(torch.int32)
+        return keys, ops.iou_counts_shared_truth(gt.contiguous(), masks, self.class_id, include_bg=True)
 
     @staticmethod
     def _ious_from_counts(keys, counts):

@@ -216,6 +216,23 @@ int asr_threshold_f32(const float* image, const float* th_mask, float* minmax_ws
 int asr_iou_counts_i32(const int32_t* truth, const int32_t* pred, int64_t* counts, int64_t per_segment, int segments,
                        int class_id, int include_bg, asr_stream_t stream);
 
+/* The same counts for num_preds prediction masks [num_preds, pixels] against ONE label map [pixels] -- the four masks of an
+ * image (standard, ASR, max-SR, mean-SR) against its ground truth, SR_single_class.py:109-120 -- without replicating it. */
+int asr_iou_counts_shared_truth_i32(const int32_t* truth, const int32_t* preds, int64_t* counts, int64_t pixels, int num_preds,
+                                    int class_id, int include_bg, asr_stream_t stream);
+
+/* min_max_normalization of whole stacks with their own global extrema, as load_SR_data applies it to the argmax / slice_max
+ * masks of an image (superres_utils.py:56-62, 183-206): per segment out = new_min + ((x - min) * (new_max - new_min)) /
+ * (max - min, or 1 when they are equal).  minmax_ws: [segments, 2] floats of scratch (receives the extrema). */
+int asr_minmax_normalize_f32(const float* x, float* out, float* minmax_ws, int64_t per_segment, int segments, float new_min,
+                             float new_max, asr_stream_t stream);
+
+/* Standard-output mask of ONE image (generate_standard_output.py:52-65: the model built with final_upsample=True,
+ * model.py:108-111, then create_mask and the class filter): bilinear half-pixel upsample of the logits [h_in, w_in, classes]
+ * to h_out x w_out, argmax over the classes (first maximum), mask = class_id where it wins, else 0 -- in one pass. */
+int asr_standard_mask_i32(const float* logits, int32_t* mask, int h_in, int w_in, int classes, int h_out, int w_out, int class_id,
+                          asr_stream_t stream);
+
 /* Per-label pixel counts for the multi-class Mean_IOU (utils.py:151-177, compute_IoU(class_id=None)):
  * counts[seg][0][l] = |truth == l|, counts[seg][1][l] = |pred == l|, counts[seg][2][l] = |truth == l and pred == l|,
  * l = 0..255 (int64, zeroed by the call); IoU_l = c2 / (c0 + c1 - c2). */

@@ -251,3 +251,42 @@ def test_sr_solve_two_kernel_backward_is_bit_identical_to_fused(dev, H, h):
                                                one_minus_beta1=np.float32(1) - b1, one_minus_beta2=np.float32(1) - b2,
                                                epsilon=eps, amsgrad=True))
     assert torch.equal(x_solve, xd)
+
+
+def test_mask_pipeline_entry_points(dev):
+    """The per-image glue of HotPath as library kernels: global min-max normalisation of a mask stack
+    (superres_utils.py:56-62,183-206), the fused standard-output mask (generate_standard_output.py:52-65 = Resizing +
+    argmax + class filter) and the IoU counts of several masks against ONE label map (SR_single_class.py:109-120)."""
+    from asr_amd import ops
+    rng = np.random.default_rng(12)
+    # min-max normalisation: argmax masks {0, 8} -> {0, 1}; a float stack; a constant stack (max == min -> den = 1)
+    stack = rng.choice(np.array([0.0, 8.0], np.float32), size=(5, 32, 32))
+    got = ops.minmax_normalize(ops.to_device(stack)).cpu().numpy()
+    assert np.array_equal(got, np.stack([o_sr.min_max_normalization(m, 0.0, 1.0, stack.min(), stack.max()) for m in stack]).astype(np.float32))
+    fl = rng.standard_normal((3, 16, 16)).astype(np.float32)
+    got = ops.minmax_normalize(ops.to_device(fl), segments=3, new_min=0.0, new_max=255.0).cpu().numpy()
+    for i in range(3):
+        np.testing.assert_allclose(got[i], o_sr.min_max_normalization(fl[i], 0.0, 255.0).astype(np.float32), rtol=0, atol=2e-5)
+    const = np.full((2, 8, 8), 3.0, np.float32)
+    assert np.array_equal(ops.minmax_normalize(ops.to_device(const)).cpu().numpy(), np.zeros_like(const))
+    # standard mask == resize (half-pixel bilinear) -> argmax (first maximum) -> class filter
+    logits = rng.standard_normal((24, 20, 21)).astype(np.float32)
+    logits[:6, :6] = 0.25                              # ties across classes: class 0 must win there
+    ld = ops.to_device(logits)
+    got = ops.standard_mask(ld, (96, 80), 8).cpu().numpy()
+    padded = torch.full((1, 24, 20, 24), -3.0e38, dtype=torch.float32, device=ld.device)
+    padded[0, :, :, :21] = ld
+    am = ops.argmax(ops.resize_bilinear(padded, (96, 80)))[0].cpu().numpy()
+    assert np.array_equal(got, np.where(am == 8, 8, 0))
+    up = torch.nn.functional.interpolate(torch.from_numpy(logits).permute(2, 0, 1)[None], size=(96, 80), mode="bilinear",
+                                         align_corners=False)[0].permute(1, 2, 0).numpy()
+    ref = np.where(np.argmax(up, axis=-1) == 8, 8, 0)
+    assert (got == ref).mean() >= 0.999 and (got == 8).any()
+    # IoU counts of four masks against one label map == the replicated-truth form
+    truth = rng.choice(np.array([0, 8, 8, 3, 255], np.int32), size=(96, 80))
+    preds = rng.choice(np.array([0, 8], np.int32), size=(4, 96, 80))
+    td, pd = ops.to_device(truth, torch.int32), ops.to_device(preds, torch.int32)
+    for bg in (False, True):
+        a = ops.iou_counts_shared_truth(td, pd, 8, include_bg=bg).cpu().numpy()
+        b = ops.iou_counts(td[None].expand(4, -1, -1).contiguous(), pd, 8, include_bg=bg, segments=4).cpu().numpy()
+        assert np.array_equal(a, b)
