@@ -17,7 +17,8 @@ LIB = os.path.join(PKG, "libasr_hip.so")
 # Diagnostic builds never replace the product library: `ASR_BUILD_VARIANT=phase` (s_memtime phase stamps in the GEMM K
 # loops, a device synchronisation after every split-f16 launch) goes to its own object directory and library; select it at
 # run time with ASR_LIB=<path> (asr_amd/_lib.py).
-VARIANTS = {"phase": ["-DASR_GEMM_PHASE_PROFILE"]}
+VARIANTS = {"phase": ["-DASR_GEMM_PHASE_PROFILE"],      # s_memtime stamps per phase of the GEMM K loops
+            "diag": ["-DASR_DIAG_KERNELS"]}                # extra experiment kernels (asr_diag_* entry points), no stamps
 
 # (source, extra flags)
 SOURCES = [

@@ -20,6 +20,7 @@
 //    consecutive logical ids, and logical ids are dealt so that consecutive ones share an XCD
 //    (private L2), using the bijective remap.
 #include "asr_common.h"
+#include <utility>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -124,7 +125,10 @@ __device__ __forceinline__ void pw_epilogue(const PwArgs& p, f32x16 (&acc)[TM][T
 // pw_epilogue for accumulators of v_mfma_f32_16x16x32_f16: acc[rt][ct] (f32x4) holds rows rt * 16 + 4 * (lane >> 4) + r
 // (r = 0..3), column ct * 16 + (lane & 15) of the wave's (RT * 16) x (CT * 16) sub-tile.  Same LDS transposition, residual
 // prefetch and 16-byte stores as pw_epilogue<..., RES_AHEAD = true>; only the staging map differs.
-template <int WM, int WN, int RT, int CT>
+// RES_DEPTH: residual pieces (of the 16 per 32-row slab) requested ahead of their use.  16 = the whole slab before its
+// accumulators go through the LDS (kernels with registers to spare); a smaller depth keeps a rolling queue -- the piece of
+// row group q + RES_DEPTH is requested when the piece of row group q has been added -- for kernels at 168 registers per wave.
+template <int WM, int WN, int RT, int CT, int RES_DEPTH = 16>
 __device__ __forceinline__ void pw_epilogue16(const PwArgs& p, f32x4 (&acc)[RT][CT], float* smem, int tile_m, int tile_n, int wave, int lane) {
     constexpr int BM = WM * RT * 16, BN = WN * CT * 16, WCOLS = CT * 16;
     constexpr int LPR = WCOLS / 4, RPI = 64 / LPR;
@@ -146,14 +150,18 @@ __device__ __forceinline__ void pw_epilogue16(const PwArgs& p, f32x4 (&acc)[RT][
 #pragma unroll
     for (int i = 0; i < RT / 2; ++i) {                         // 32-row slabs
         const long long m_base = (long long)tile_m * BM + (wm * RT + 2 * i) * 16;
-        f32x4 rv[32 / RPI];
-        if (res_vec) {
-            const float* rbase = p.res + (n < p.N ? n : 0);
+        constexpr int NQ = 32 / RPI;
+        static_assert(RES_DEPTH >= 1 && RES_DEPTH <= NQ, "RES_DEPTH out of range");
+        f32x4 rv[RES_DEPTH];
+        const float* const rbase = res_vec ? p.res + (n < p.N ? n : 0) : nullptr;
+        auto request = [&](int q) {                            // clamped address, no branch around the load
+            const long long m = m_base + q * RPI + r_in;
+            rv[q % RES_DEPTH] = *reinterpret_cast<const f32x4*>(rbase + (m < p.M ? m : p.M - 1) * p.ldres);
+        };
+        constexpr bool kRequestFirst = RES_DEPTH == NQ;        // a short queue is requested behind the staging stores, when
+        if (res_vec && kRequestFirst) {                        // this slab's accumulators no longer occupy registers
 #pragma unroll
-            for (int q = 0; q < 32 / RPI; ++q) {
-                const long long m = m_base + q * RPI + r_in;
-                rv[q] = *reinterpret_cast<const f32x4*>(rbase + (m < p.M ? m : p.M - 1) * p.ldres);
-            }
+            for (int q = 0; q < RES_DEPTH; ++q) request(q);
         }
 #pragma unroll
         for (int h2 = 0; h2 < 2; ++h2)
@@ -166,14 +174,24 @@ __device__ __forceinline__ void pw_epilogue16(const PwArgs& p, f32x4 (&acc)[RT][
                     if (p.relu == 2) v = fminf(v, 6.f);
                     stage[(h2 * 16 + 4 * q4 + r) * WCOLS + ct * 16 + l16] = v;
                 }
+        if (res_vec && !kRequestFirst) {
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int q = 0; q < 32 / RPI; ++q) {
+            for (int q = 0; q < RES_DEPTH; ++q) request(q);
+        }
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
             const int r = q * RPI + r_in;
             const long long m = m_base + r;
             f32x4 v = *reinterpret_cast<const f32x4*>(stage + r * WCOLS + c4 * 4);
+            f32x4 rq = {0.f, 0.f, 0.f, 0.f};
+            if (res_vec) {
+                rq = rv[q % RES_DEPTH];
+                if (q + RES_DEPTH < NQ) request(q + RES_DEPTH);
+            }
             if (m < p.M && n < p.N) {
                 if (vec_ok) {
-                    if (p.res) v += rv[q];
+                    if (p.res) v += rq;
                     *reinterpret_cast<f32x4*>(p.y + m * p.ldy + n) = v;
                 } else {
 #pragma unroll
@@ -577,8 +595,7 @@ __global__ __launch_bounds__(WM * WN * 64) void pw_gemm_f16x3_kernel(PwArgs p) {
 // one 128-byte line [hi(32) | lo(32)].  Both operands then reach LDS by LDS-DMA (global_load_lds_dwordx4): no staging
 // registers, no conversion VALU, no ds_write, which is what lets a 256 x 256 tile (half the staged bytes per flop of
 // 128 x 128: the CU takes in only ~20-30 B/clk from L2 under load, DESIGN.md "GEMM phase profile") run with two LDS
-// stages at 2 waves per SIMD.  8 waves, each 64 x 128 of the tile; BK = 32; same MFMA sequence per accumulator as the
-// in-kernel-split kernel, so the results are bit-identical to it.
+// stages.  8 MFMA waves, each 64 x 128 of the tile; BK = 32.
 //   LDS stage (64 KB): A [256 rows][8 slots of 16 B: hi oct 0-3, lo oct 0-3], slot XOR-swizzled by (row >> 1) & 7 --
 //   applied on the per-lane SOURCE address, the DMA destination is lane-linear --, then B_hi, B_lo [4 oct][256 col][8].
 // =================================================================================================
@@ -589,6 +606,179 @@ __device__ __forceinline__ void glds16(const void* g, void* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((asr_gbl_ptr)g, (asr_lds_ptr)lds_wave_base, 16, 0, 0);
 }
 
+// The workgroup's twelve waves have FIXED ROLES.  Round 1's form of this kernel (8 waves that each requested their own 8
+// pieces of the next stage and then issued their MFMAs; now diagnostic-only, below) left the matrix pipe idle for the ~1000
+// cycles per K-step in which all waves sat in the vector-memory issue queue: a wave pays ~100-150 cycles per 1 KiB LDS-DMA
+// piece whoever issues it, and a wave that is issuing cannot issue MFMAs.  Here waves 0-7 only read fragments and issue
+// MFMAs (no vector-memory instruction inside the K loop); waves 8-11 -- one per SIMD -- only request: 16 pieces each per
+// K-step (~1700 cycles of issue + ~1300 until the last piece has landed, under the ~3100 cycles the SIMD's two MFMA waves
+// need), then meet the MFMA waves at the K-step's barrier.  Three waves per SIMD leave 168 registers per wave: the MFMA
+// waves hold the 128 accumulators and walk their 64 x 128 tile in two 32-row halves (the A fragments of two row tiles at a
+// time, the B fragments double-buffered one column tile ahead; scheduling barriers keep the compiler from hoisting every
+// read, which would spill).  Same MFMA sequence per accumulator as the 8-wave form => bit-identical results; K-step 4100 ->
+// 3600 cycles, 4-6 % less wall time launch for launch (tools/ab_presplit_lw.py: the two forms interleaved in one process;
+// timed in separate processes the chip's clock drift hides the difference), profiles/r02_gemm_loader_wave_experiment.txt.
+// =================================================================================================
+template <typename F, int... I>
+__device__ __forceinline__ void asr_static_for_impl(F& f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void asr_static_for(F& f) {
+    asr_static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+template <int PIECES_PER_LOADER = 16>
+__global__ __launch_bounds__(768, 3) void pw_gemm_f16x3_pre_lw_kernel(PwArgs p) {
+    constexpr int BM = 256, BN = 256, WN = 2, RT = 4, CT = 8;
+    constexpr int A_BYTES = BM * 128, B_BYTES = 4 * BN * 16, STAGE_BYTES = A_BYTES + 2 * B_BYTES;
+    constexpr int A_PIECES = A_BYTES / 1024;                   // 32 pieces of 64 lanes x 16 B; then 32 B pieces (hi plane, lo plane)
+    static_assert(4 * PIECES_PER_LOADER * 1024 == STAGE_BYTES, "four loader waves cover one stage");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    char* const lds = reinterpret_cast<char*>(smem);
+
+    const int nwg = gridDim.x, orig = blockIdx.x;
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
+    const int lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+    const int tile_m = lid / p.tiles_n, tile_n = lid % p.tiles_n;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int KT = p.Kpad / BK;
+
+    if (wave >= 8) {
+        // ---- loader wave: pieces (wave - 8) * 16 .. + 15 of every stage ------------------------------------------
+        const int first = (wave - 8) * PIECES_PER_LOADER;
+        const char* src[PIECES_PER_LOADER];
+        long long kstep[2];                                     // byte advance per K-step: A pieces, B pieces
+        kstep[0] = 128;
+        kstep[1] = (long long)4 * p.Npad * 16;
+        const long long plane_bytes = (long long)p.Kpad * p.Npad * 2;
+#pragma unroll
+        for (int j = 0; j < PIECES_PER_LOADER; ++j) {
+            const int pi = first + j;
+            if (pi < A_PIECES) {                                // A: (row q >> 3, LDS slot q & 7 holding global slot ^ swizzle)
+                const int q = pi * 64 + lane, row = q >> 3, slot = (q & 7) ^ ((row >> 1) & 7);
+                long long m = (long long)tile_m * BM + row;
+                if (m >= p.M) m = p.M - 1;                      // rows past the end re-read the last row; never stored
+                src[j] = reinterpret_cast<const char*>(p.x) + (m * p.ldx) * 128 + slot * 16;
+            } else {                                            // B: plane (hi, lo), k-octet, column
+                const int qb = (pi - A_PIECES) * 64 + lane, plane = qb >> 10, r = qb & 1023, oct = r >> 8, col = r & 255;
+                src[j] = reinterpret_cast<const char*>(p.wp) + plane * plane_bytes +
+                         (((long long)oct * p.Npad) + (long long)tile_n * BN + col) * 16;
+            }
+        }
+        auto issue = [&](int kt, int stage) {
+            char* const st = lds + stage * STAGE_BYTES + first * 1024;
+#pragma unroll
+            for (int j = 0; j < PIECES_PER_LOADER; ++j)
+                glds16(src[j] + kt * kstep[(first + j) < A_PIECES ? 0 : 1], st + j * 1024);
+        };
+        issue(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+#ifdef ASR_GEMM_PHASE_PROFILE
+        long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        long long tprev = (long long)__builtin_readcyclecounter();
+#endif
+        for (int kt = 0; kt < KT; ++kt) {
+            if (kt + 1 < KT) issue(kt + 1, (kt + 1) & 1);      // the other stage: last read before the previous barrier
+            PHASE_MARK(0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // landed before anyone is released to read it
+            PHASE_MARK(1);
+            __builtin_amdgcn_s_barrier();
+            PHASE_MARK(2);
+        }
+#ifdef ASR_GEMM_PHASE_PROFILE
+        if (tid == 512 && orig < ASR_PHASE_BLOCKS)
+            for (int i = 0; i < 3; ++i) g_phase_cycles[orig * 16 + 8 + i] = ph[i];
+#endif
+        return;
+    }
+
+    // ---- MFMA wave ------------------------------------------------------------------------------------------------
+    const int wm = wave / WN, wn = wave % WN;
+    const int l16 = lane & 15, oct = lane >> 4;                // A: row = l16, k = 8 oct ..; B: column = l16, same k
+    f32x4 acc[RT][CT];
+#pragma unroll
+    for (int i = 0; i < RT; ++i)
+#pragma unroll
+        for (int j = 0; j < CT; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
+
+#ifdef ASR_GEMM_PHASE_PROFILE
+    long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long tprev = (long long)__builtin_readcyclecounter();
+#endif
+    __builtin_amdgcn_s_barrier();                              // stage 0 landed (the loaders waited for it)
+    PHASE_MARK(0);
+#ifdef ASR_GEMM_PHASE_PROFILE
+    const long long loop_c0 = (long long)__builtin_readcyclecounter(), loop_r0 = (long long)__builtin_amdgcn_s_memrealtime();
+#endif
+    for (int kt = 0; kt < KT; ++kt) {
+        const char* const st = lds + (kt & 1) * STAGE_BYTES;
+        // 2 halves x 8 column tiles = 16 groups of 6 MFMAs; the fragments of group g + 1 are requested before the MFMAs of
+        // group g (one B double buffer, the A pair of the second half is requested under the last group of the first),
+        // and a scheduling barrier per group keeps the compiler from hoisting every read to the top (it would need 160
+        // fragment registers and spill).
+        f16x8 ah[2], al[2], bh[2], bl[2];
+        auto read_a = [&](int half, int i) {                   // hi / lo fragments of row tile 2 * half + i
+            const int row = (wm * RT + 2 * half + i) * 16 + l16, swz = (row >> 1) & 7;
+            ah[i] = *reinterpret_cast<const f16x8*>(st + row * 128 + ((oct ^ swz) << 4));
+            al[i] = *reinterpret_cast<const f16x8*>(st + row * 128 + (((4 + oct) ^ swz) << 4));
+        };
+        auto read_b = [&](int j, int buf) {
+            const int col = (wn * CT + j) * 16 + l16;
+            bh[buf] = *reinterpret_cast<const f16x8*>(st + A_BYTES + (oct * BN + col) * 16);
+            bl[buf] = *reinterpret_cast<const f16x8*>(st + A_BYTES + B_BYTES + (oct * BN + col) * 16);
+        };
+        read_a(0, 0);
+        read_a(0, 1);
+        read_b(0, 0);
+        auto group = [&](auto G) {
+            constexpr int g = decltype(G)::value, half = g / CT, j = g % CT;
+            constexpr bool last_of_half0 = g == CT - 1;
+            if (g + 1 < 2 * CT) read_b((g + 1) % CT, (g + 1) & 1);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                f32x4& a4 = acc[2 * half + i][j];
+                a4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh[g & 1], a4, 0, 0, 0);
+                a4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl[g & 1], a4, 0, 0, 0);
+                a4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bh[g & 1], a4, 0, 0, 0);
+                if (last_of_half0) read_a(1, i);               // the second half's row tile into the registers just consumed
+            }
+            // order inside the group: the next group's fragment reads first, then the MFMAs (the A refills behind their rows)
+            if (g + 1 < 2 * CT) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+            if (last_of_half0) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+            if (last_of_half0) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        asr_static_for<2 * CT>(group);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // this wave's reads of the stage are done
+        PHASE_MARK(2);
+        __builtin_amdgcn_s_barrier();
+        PHASE_MARK(6);
+    }
+#ifdef ASR_GEMM_PHASE_PROFILE
+    if (tid == 0 && orig < ASR_PHASE_BLOCKS) {
+        g_phase_cycles[orig * 16 + 11] = (long long)__builtin_readcyclecounter() - loop_c0;
+        g_phase_cycles[orig * 16 + 12] = (long long)__builtin_amdgcn_s_memrealtime() - loop_r0;
+    }
+#endif
+    pw_epilogue16<4, WN, RT, CT, 4>(p, acc, smem, tile_m, tile_n, wave, lane);
+#ifdef ASR_GEMM_PHASE_PROFILE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    PHASE_MARK(7);
+    if (tid == 0 && orig < ASR_PHASE_BLOCKS)
+        for (int i = 0; i < 8; ++i) g_phase_cycles[orig * 16 + i] = ph[i];
+#endif
+}
+
+#ifdef ASR_DIAG_KERNELS
+// ---- diagnostic build only (csrc/build.py, ASR_BUILD_VARIANT=diag): round 1's form of this kernel -- 8 waves that each
+//      request their own 8 pieces and then issue their MFMAs -- kept so that tools/ab_presplit_lw.py can A/B the two in one
+//      process; never part of libasr_hip.so --------------------------------------------------------------------------------
 template <int WM, int WN, int TM, int TN>
 __global__ __launch_bounds__(WM * WN * 64, 2) void pw_gemm_f16x3_pre_kernel(PwArgs p) {
     constexpr int NT = WM * WN * 64, BM = WM * TM * 32, BN = WN * TN * 32;
@@ -705,6 +895,9 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void pw_gemm_f16x3_pre_kernel(PwAr
         for (int i = 0; i < 8; ++i) g_phase_cycles[orig * 16 + i] = ph[i];
 #endif
 }
+
+
+#endif  // ASR_DIAG_KERNELS
 
 // w [K][N] f32 -> two half planes [Kpad/8][Npad][8] (hi then lo), zero padded
 __global__ __launch_bounds__(256) void pack_weights_f16x3_kernel(const float* __restrict__ w, _Float16* __restrict__ wp, int K,
@@ -940,10 +1133,10 @@ extern "C" int asr_pwconv_mfma_f16x3_presplit(const void* x_split, const float* 
     const long long nwg = asr_cdiv(m, bm) * a.tiles_n;
     ASR_REQUIRE(nwg <= 0x7fffffffLL, "asr_pwconv_mfma_f16x3_presplit: grid too large");
     constexpr size_t lds = 2 * (bm * 128 + 2 * 4 * bn * 16);
-    auto kern = pw_gemm_f16x3_pre_kernel<4, 2, 2, 4>;
+    auto kern = pw_gemm_f16x3_pre_lw_kernel<16>;
     static AsrDeviceOnce once;
     ASR_HIP_CHECK(asr_allow_dynamic_lds(once, reinterpret_cast<const void*>(kern), (int)lds));
-    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(512), lds, asr_stream(stream), a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(768), lds, asr_stream(stream), a);
     ASR_LAUNCH_CHECK();
 #ifdef ASR_GEMM_PHASE_PROFILE
     {
@@ -955,12 +1148,11 @@ extern "C" int asr_pwconv_mfma_f16x3_presplit(const void* x_split, const float* 
         for (long long b = 0; b < nb; ++b)
             for (int i = 0; i < 16; ++i) mean[i] += (double)host[b * 16 + i] / (double)nb;
         const int kt = a.Kpad / 32;
-        fprintf(stderr, "[phase-pre] M=%lld K=%d N=%d blocks=%lld ksteps=%d | prologue %.0f | per k-step: issue %.0f  lds+mfma %.0f  "
-                        "vmwait %.0f  barrier %.0f | epilogue (stores drained) %.0f | block total %.0f cycles\n",
-                (long long)a.M, a.K, a.N, nwg, kt, mean[0], mean[1] / kt, mean[2] / kt, mean[3] / kt, mean[6] / kt, mean[7],
-                mean[0] + mean[1] + mean[2] + mean[3] + mean[6] + mean[7]);
-        fprintf(stderr, "[phase-pre clock] K loop %.0f cycles = %.2f us -> %.3f GHz in-kernel | per k-step %.0f\n", mean[11], mean[12] / 100.0,
-                mean[12] > 0 ? mean[11] / (mean[12] * 10.0) : 0.0, mean[11] / kt);
+        fprintf(stderr, "[phase-pre] M=%lld K=%d N=%d blocks=%lld ksteps=%d | mfma wave 0: prologue %.0f | per k-step: reads+mfma %.0f  barrier %.0f | "
+                        "epilogue %.0f || loader wave 8 per k-step: issue %.0f  landing wait %.0f  barrier %.0f || K loop %.0f cycles = %.2f us -> "
+                        "%.3f GHz in-kernel, per k-step %.0f\n", (long long)a.M, a.K, a.N, nwg, kt, mean[0], mean[2] / kt, mean[6] / kt, mean[7],
+                mean[8] / kt, mean[9] / kt, mean[10] / kt, mean[11], mean[12] / 100.0, mean[12] > 0 ? mean[11] / (mean[12] * 10.0) : 0.0,
+                mean[11] / kt);
     }
 #endif
     return ASR_OK;
@@ -984,3 +1176,27 @@ extern "C" int asr_conv3x3_mfma_f16x3(const float* x, const float* w_packed, con
     a.stride = stride; a.pad = pad; a.dil = dil;
     return launch_f16x3(a, cout <= 64 ? 2 : 1, stream);
 }
+
+#ifdef ASR_DIAG_KERNELS
+// asr_pwconv_mfma_f16x3_presplit's arguments on round 1's 8-wave kernel (diagnostic library only; not in include/asr_hip.h)
+extern "C" int asr_diag_pwconv_presplit_8w(const void* x_split, const float* w_packed, const float* bias, const float* residual,
+                                           float* y, int64_t m, int k, int n, int ldx_chunks, int ldy, int ldres, int relu,
+                                           asr_stream_t stream) {
+    ASR_REQUIRE(x_split && w_packed && y && m > 0 && k > 0 && n > 0, "asr_diag_pwconv_presplit_8w: bad arguments");
+    PwArgs a{};
+    a.x = reinterpret_cast<const float*>(x_split); a.wp = w_packed; a.bias = bias; a.res = residual; a.y = y;
+    a.M = m; a.K = k; a.N = n; a.Npad = round_up(n, 128); a.Kpad = round_up(k, BK);
+    a.ldx = ldx_chunks; a.ldy = ldy; a.ldres = ldres; a.relu = relu;
+    a.taps = 1; a.cin = k; a.stride = 1; a.pad = 0; a.dil = 1;
+    ASR_UNSUPPORTED(a.Npad % 256 != 0, "asr_diag_pwconv_presplit_8w: ceil128(n) must be a multiple of 256");
+    a.tiles_n = (int)asr_cdiv(n, 256);
+    const long long nwg = asr_cdiv(m, 256) * a.tiles_n;
+    constexpr size_t lds = 2 * (256 * 128 + 2 * 4 * 256 * 16);
+    auto kern8 = pw_gemm_f16x3_pre_kernel<4, 2, 2, 4>;
+    static AsrDeviceOnce once;
+    ASR_HIP_CHECK(asr_allow_dynamic_lds(once, reinterpret_cast<const void*>(kern8), (int)lds));
+    hipLaunchKernelGGL(kern8, dim3((unsigned)nwg), dim3(512), lds, asr_stream(stream), a);
+    ASR_LAUNCH_CHECK();
+    return ASR_OK;
+}
+#endif
