@@ -628,244 +628,6 @@ __device__ __forceinline__ void asr_static_for(F& f) {
     asr_static_for_impl(f, std::make_integer_sequence<int, N>{});
 }
 
-// =================================================================================================
-// Persistent form: one workgroup per CU walks its tiles in ONE flat loop over (tile, K-step) pairs.  The loader waves run
-// one K-step ahead across tile boundaries, so while the MFMA waves are in a tile's epilogue the first TWO K-steps of their
-// next tile are already being requested / landing -- the per-tile prologue (~5.5 K cycles, 5 % of a 728-deep tile, 10 %
-// of a 256-deep one) disappears and the epilogue's HBM stores run beside the next tile's operand loads.  For that the
-// epilogue no longer borrows the stage buffers: it transposes through 32 KB of its own (4 KB per MFMA wave: 16 rows x 64
-// columns at a time), which brings the workgroup to the CU's full 160 KB of LDS.
-//   Tiles -> workgroups: workgroup w sits on XCD w % 8 (round-robin placement, speed only); XCD x owns the contiguous
-//   tile range [x T / 8, (x + 1) T / 8) and its workgroups take those tiles round-robin, so the tiles in flight on an XCD
-//   at any time are consecutive ones -- the N-tiles of an A row panel share that XCD's L2, as in the one-tile-per-workgroup
-//   form's remap.  Same MFMA sequence per accumulator => bit-identical results.
-// =================================================================================================
-constexpr int kPreEpiBytes = 8 * 4096;                         // epilogue staging: 8 MFMA waves x (16 rows x 64 columns x 4 B)
-
-// One 16 x 64 chunk of a wave's accumulators (row tile rt, column tiles 4 * ch .. + 3) -> bias, ReLU, residual, 16-byte stores.
-template <int RT, int CT>
-__device__ __forceinline__ void pw_epilogue16_chunk(const PwArgs& p, f32x4 (&acc)[RT][CT], int rt, int ch, float* stage,
-                                                    const float (&bv)[CT], long long m_wave, int n_wave, int lane, bool vec_ok) {
-    const int l16 = lane & 15, q4 = lane >> 4;
-    const int c4 = lane & 15, r_in = lane >> 4;                // read-back: 16 lanes per row, 4 rows per wave-instruction
-    const int n = n_wave + ch * 64 + c4 * 4;
-    const long long m_base = m_wave + rt * 16;
-#pragma unroll
-    for (int c = 0; c < 4; ++c)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float v = acc[rt][4 * ch + c][r] + bv[4 * ch + c];
-            if (p.relu) v = fmaxf(v, 0.f);
-            if (p.relu == 2) v = fminf(v, 6.f);
-            stage[(4 * q4 + r) * 64 + c * 16 + l16] = v;
-        }
-    const bool res_vec = vec_ok && p.res != nullptr;
-    f32x4 rv[4];
-    if (res_vec) {                                             // clamped addresses, no branch around the loads
-        const float* rbase = p.res + (n < p.N ? n : 0);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const long long m = m_base + q * 4 + r_in;
-            rv[q] = *reinterpret_cast<const f32x4*>(rbase + (m < p.M ? m : p.M - 1) * p.ldres);
-        }
-    }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int r = q * 4 + r_in;
-        const long long m = m_base + r;
-        f32x4 v = *reinterpret_cast<const f32x4*>(stage + r * 64 + c4 * 4);
-        if (m < p.M && n < p.N) {
-            if (vec_ok) {
-                if (p.res) v += rv[q];
-                *reinterpret_cast<f32x4*>(p.y + m * p.ldy + n) = v;
-            } else {
-#pragma unroll
-                for (int t = 0; t < 4; ++t)
-                    if (n + t < p.N) {
-                        float o = v[t];
-                        if (p.res) o += p.res[m * p.ldres + n + t];
-                        p.y[m * p.ldy + n + t] = o;
-                    }
-            }
-        }
-    }
-}
-
-template <int PIECES_PER_LOADER = 16>
-__global__ __launch_bounds__(768, 3) void pw_gemm_f16x3_pre_persist_kernel(PwArgs p, int tiles_total) {
-    constexpr int BM = 256, BN = 256, WN = 2, RT = 4, CT = 8;
-    constexpr int A_BYTES = BM * 128, B_BYTES = 4 * BN * 16, STAGE_BYTES = A_BYTES + 2 * B_BYTES;
-    constexpr int A_PIECES = A_BYTES / 1024;
-    static_assert(4 * PIECES_PER_LOADER * 1024 == STAGE_BYTES, "four loader waves cover one stage");
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    char* const lds = reinterpret_cast<char*>(smem);
-
-    // this workgroup's tiles: t_first, t_first + t_step, ... < t_end (all wave-uniform)
-    const int gx = gridDim.x >> 3, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int t_begin = (int)(((long long)xcd * tiles_total) >> 3), t_end = (int)(((long long)(xcd + 1) * tiles_total) >> 3);
-    const int t_first = t_begin + slot, t_step = gx;
-    if (t_first >= t_end) return;                              // (a small launch: more workgroups than tiles on this XCD)
-    const int my_tiles = (t_end - t_first + t_step - 1) / t_step;
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int KT = p.Kpad / BK;
-    const int total = my_tiles * KT;                           // K-steps of the flat loop
-
-    if (wave >= 8) {
-        // ---- loader wave: pieces (wave - 8) * 16 .. + 15 of every stage, one K-step ahead of the MFMA waves ----------
-        const int first = (wave - 8) * PIECES_PER_LOADER;
-        const char* src[PIECES_PER_LOADER];
-        long long kstep[2];
-        kstep[0] = 128;
-        kstep[1] = (long long)4 * p.Npad * 16;
-        const long long plane_bytes = (long long)p.Kpad * p.Npad * 2;
-        auto set_tile = [&](int tile) {
-            const int tile_m = tile / p.tiles_n, tile_n = tile % p.tiles_n;
-#pragma unroll
-            for (int j = 0; j < PIECES_PER_LOADER; ++j) {
-                const int pi = first + j;
-                if (pi < A_PIECES) {                            // A: (row q >> 3, LDS slot q & 7 holding global slot ^ swizzle)
-                    const int q = pi * 64 + lane, row = q >> 3, sl = (q & 7) ^ ((row >> 1) & 7);
-                    long long m = (long long)tile_m * BM + row;
-                    if (m >= p.M) m = p.M - 1;                  // rows past the end re-read the last row; never stored
-                    src[j] = reinterpret_cast<const char*>(p.x) + (m * p.ldx) * 128 + sl * 16;
-                } else {                                        // B: plane (hi, lo), k-octet, column
-                    const int qb = (pi - A_PIECES) * 64 + lane, plane = qb >> 10, r = qb & 1023, oct = r >> 8, col = r & 255;
-                    src[j] = reinterpret_cast<const char*>(p.wp) + plane * plane_bytes +
-                             (((long long)oct * p.Npad) + (long long)tile_n * BN + col) * 16;
-                }
-            }
-        };
-        auto issue = [&](int kt, int stage) {
-            char* const st = lds + stage * STAGE_BYTES + first * 1024;
-#pragma unroll
-            for (int j = 0; j < PIECES_PER_LOADER; ++j)
-                glds16(src[j] + kt * kstep[(first + j) < A_PIECES ? 0 : 1], st + j * 1024);
-        };
-        int tile = t_first, kt_next = 0;                        // (tile, kt_next): the K-step to request next
-        set_tile(tile);
-        issue(0, 0);
-        kt_next = 1;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        for (int g = 0; g < total; ++g) {
-            if (g + 1 < total) {
-                if (kt_next == KT) {                            // the next K-step opens the next tile
-                    kt_next = 0;
-                    tile += t_step;
-                    set_tile(tile);
-                }
-                issue(kt_next, (g + 1) & 1);                    // the other stage: last read before the previous barrier
-                ++kt_next;
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // landed before anyone is released to read it
-            __builtin_amdgcn_s_barrier();
-        }
-        return;
-    }
-
-    // ---- MFMA wave ------------------------------------------------------------------------------------------------
-    const int wm = wave / WN, wn = wave % WN;
-    float* const stage = reinterpret_cast<float*>(lds + 2 * STAGE_BYTES) + wave * 1024;
-    const bool vec_ok = ((p.N & 3) == 0) && ((p.ldy & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.y) & 15) == 0) &&
-                        (!p.res || (((p.ldres & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.res) & 15) == 0)));
-    f32x4 acc[RT][CT];
-#pragma unroll
-    for (int i = 0; i < RT; ++i)
-#pragma unroll
-        for (int j = 0; j < CT; ++j)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
-
-    int tile = t_first, kt = 0;
-    __builtin_amdgcn_s_barrier();                              // the first stage has landed (the loaders waited for it)
-    for (int g = 0; g < total; ++g) {
-        const char* const st = lds + (g & 1) * STAGE_BYTES;
-        // 2 halves x 8 column tiles = 16 groups of 6 MFMAs; the fragments of group g + 1 are requested before the MFMAs of
-        // group g (one B double buffer, the A pair of the second half refills the registers the first half just consumed),
-        // and a scheduling barrier per group keeps the compiler from hoisting every read to the top (it would need 160
-        // fragment registers and spill).
-        // three lane-dependent base addresses per K-step; every fragment is a compile-time offset from one of them (row
-        // tile i: + 2048 i -- the swizzle (row >> 1) & 7 does not depend on i --, lo = the hi slot with bit 6 flipped,
-        // column tile j: + 256 j, lo plane: + B_BYTES)
-        // The lane-dependent parts are RE-DERIVED from the lane id every K-step (a handful of VALU instructions): with 128
-        // accumulators and 32 fragment registers of the 168 in use, anything else kept alive across the loop is spilled.
-        int lane_k = lane;
-        asm volatile("" : "+v"(lane_k));                       // opaque to loop-invariant code motion
-        const int l16 = lane_k & 15, oct = lane_k >> 4;        // A: row = l16, k = 8 oct ..; B: column = l16, same k
-        const unsigned a_hi0 = (unsigned)((wm * RT * 16 + l16) * 128 + ((oct ^ ((l16 >> 1) & 7)) << 4));
-        const unsigned b0 = (unsigned)(A_BYTES + (oct * BN + wn * CT * 16 + l16) * 16);
-        f16x8 ah[2], al[2], bh[2], bl[2];
-        const char* const pa_hi = st + a_hi0;
-        const char* const pa_lo = st + (a_hi0 ^ 64u);
-        const char* const pb = st + b0;
-        auto read_a = [&](int half, int i) {                   // hi / lo fragments of row tile 2 * half + i
-            ah[i] = *reinterpret_cast<const f16x8*>(pa_hi + (2 * half + i) * 2048);
-            al[i] = *reinterpret_cast<const f16x8*>(pa_lo + (2 * half + i) * 2048);
-        };
-        auto read_b = [&](int j, int buf) {
-            bh[buf] = *reinterpret_cast<const f16x8*>(pb + j * 256);
-            bl[buf] = *reinterpret_cast<const f16x8*>(pb + B_BYTES + j * 256);
-        };
-        read_a(0, 0);
-        read_a(0, 1);
-        read_b(0, 0);
-        auto group = [&](auto G) {
-            constexpr int gi = decltype(G)::value, half = gi / CT, j = gi % CT;
-            constexpr bool last_of_half0 = gi == CT - 1;
-            if (gi + 1 < 2 * CT) read_b((gi + 1) % CT, (gi + 1) & 1);
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                f32x4& a4 = acc[2 * half + i][j];
-                a4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh[gi & 1], a4, 0, 0, 0);
-                a4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl[gi & 1], a4, 0, 0, 0);
-                a4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bh[gi & 1], a4, 0, 0, 0);
-                if (last_of_half0) read_a(1, i);               // the second half's row tile into the registers just consumed
-            }
-            if (gi + 1 < 2 * CT) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
-            if (last_of_half0) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
-            if (last_of_half0) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        };
-        asr_static_for<2 * CT>(group);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // this wave's reads of the stage are done
-        __builtin_amdgcn_s_barrier();
-        if (++kt == KT) {
-            // ---- tile finished: epilogue through this wave's private 4 KB, then the next tile (whose first two K-steps the
-            //      loaders have been requesting since the barrier above)
-            int lane_e = lane;
-            asm volatile("" : "+v"(lane_e));
-            const int tile_m = tile / p.tiles_n, tile_n = tile % p.tiles_n;
-            const int n_wave = tile_n * BN + wn * (CT * 16);
-            const long long m_wave = (long long)tile_m * BM + wm * (RT * 16);
-            float bv[CT];
-#pragma unroll
-            for (int ct = 0; ct < CT; ++ct) {
-                const int nj = n_wave + ct * 16 + (lane_e & 15);
-                bv[ct] = (p.bias && nj < p.N) ? p.bias[nj] : 0.f;
-            }
-#pragma unroll
-            for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-                for (int ch = 0; ch < 2; ++ch) pw_epilogue16_chunk<RT, CT>(p, acc, rt, ch, stage, bv, m_wave, n_wave, lane_e, vec_ok);
-#pragma unroll
-            for (int i = 0; i < RT; ++i)
-#pragma unroll
-                for (int j = 0; j < CT; ++j)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
-            kt = 0;
-            tile += t_step;
-        }
-    }
-}
-
-#ifdef ASR_DIAG_KERNELS
-// ---- diagnostic build only (csrc/build.py, ASR_BUILD_VARIANT=diag), never part of libasr_hip.so: the two earlier forms of
-//      this kernel, kept so that tools/ab_presplit_lw.py can A/B all three in one process --
-//      (1) loader waves, one tile per workgroup (epilogue through the stage buffers, a prologue per tile);
-//      (0) round 1's form: 8 waves that each request their own 8 pieces and then issue their MFMAs ------------------------
 template <int PIECES_PER_LOADER = 16>
 __global__ __launch_bounds__(768, 3) void pw_gemm_f16x3_pre_lw_kernel(PwArgs p) {
     constexpr int BM = 256, BN = 256, WN = 2, RT = 4, CT = 8;
@@ -1013,6 +775,10 @@ __global__ __launch_bounds__(768, 3) void pw_gemm_f16x3_pre_lw_kernel(PwArgs p) 
 #endif
 }
 
+#ifdef ASR_DIAG_KERNELS
+// ---- diagnostic build only (csrc/build.py, ASR_BUILD_VARIANT=diag), never part of libasr_hip.so: round 1's form of this
+//      kernel -- 8 waves that each request their own 8 pieces and then issue their MFMAs -- kept so that
+//      tools/ab_presplit_lw.py can A/B the two in one process -------------------------------------------------------------
 template <int WM, int WN, int TM, int TN>
 __global__ __launch_bounds__(WM * WN * 64, 2) void pw_gemm_f16x3_pre_kernel(PwArgs p) {
     constexpr int NT = WM * WN * 64, BM = WM * TM * 32, BN = WN * TN * 32;
@@ -1366,15 +1132,11 @@ extern "C" int asr_pwconv_mfma_f16x3_presplit(const void* x_split, const float* 
     a.tiles_n = (int)asr_cdiv(n, bn);
     const long long nwg = asr_cdiv(m, bm) * a.tiles_n;
     ASR_REQUIRE(nwg <= 0x7fffffffLL, "asr_pwconv_mfma_f16x3_presplit: grid too large");
-    constexpr size_t lds = 2 * (bm * 128 + 2 * 4 * bn * 16) + kPreEpiBytes;      // 160 KB: the whole CU
-    auto kern = pw_gemm_f16x3_pre_persist_kernel<16>;
+    constexpr size_t lds = 2 * (bm * 128 + 2 * 4 * bn * 16);
+    auto kern = pw_gemm_f16x3_pre_lw_kernel<16>;
     static AsrDeviceOnce once;
     ASR_HIP_CHECK(asr_allow_dynamic_lds(once, reinterpret_cast<const void*>(kern), (int)lds));
-    const int cus = asr_device_cu_count();
-    ASR_REQUIRE(cus >= 8, "asr_pwconv_mfma_f16x3_presplit: cannot query the device");
-    const long long per_xcd = asr_cdiv(nwg, 8);
-    const int gx = (int)(per_xcd < cus / 8 ? per_xcd : cus / 8);          // workgroups per XCD: one per CU, or fewer tiles
-    hipLaunchKernelGGL(kern, dim3((unsigned)(8 * gx)), dim3(768), lds, asr_stream(stream), a, (int)nwg);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(768), lds, asr_stream(stream), a);
     ASR_LAUNCH_CHECK();
 #ifdef ASR_GEMM_PHASE_PROFILE
     {
@@ -1416,33 +1178,24 @@ extern "C" int asr_conv3x3_mfma_f16x3(const float* x, const float* w_packed, con
 }
 
 #ifdef ASR_DIAG_KERNELS
-// asr_pwconv_mfma_f16x3_presplit's arguments on an earlier form of the kernel (diagnostic library only; not in
-// include/asr_hip.h): variant 0 = round 1's 8-wave kernel, 1 = loader waves with one tile per workgroup
-extern "C" int asr_diag_pwconv_presplit(int variant, const void* x_split, const float* w_packed, const float* bias,
-                                        const float* residual, float* y, int64_t m, int k, int n, int ldx_chunks, int ldy,
-                                        int ldres, int relu, asr_stream_t stream) {
-    ASR_REQUIRE(x_split && w_packed && y && m > 0 && k > 0 && n > 0 && (variant == 0 || variant == 1),
-                "asr_diag_pwconv_presplit: bad arguments");
+// asr_pwconv_mfma_f16x3_presplit's arguments on round 1's 8-wave kernel (diagnostic library only; not in include/asr_hip.h)
+extern "C" int asr_diag_pwconv_presplit_8w(const void* x_split, const float* w_packed, const float* bias, const float* residual,
+                                           float* y, int64_t m, int k, int n, int ldx_chunks, int ldy, int ldres, int relu,
+                                           asr_stream_t stream) {
+    ASR_REQUIRE(x_split && w_packed && y && m > 0 && k > 0 && n > 0, "asr_diag_pwconv_presplit_8w: bad arguments");
     PwArgs a{};
     a.x = reinterpret_cast<const float*>(x_split); a.wp = w_packed; a.bias = bias; a.res = residual; a.y = y;
     a.M = m; a.K = k; a.N = n; a.Npad = round_up(n, 128); a.Kpad = round_up(k, BK);
     a.ldx = ldx_chunks; a.ldy = ldy; a.ldres = ldres; a.relu = relu;
     a.taps = 1; a.cin = k; a.stride = 1; a.pad = 0; a.dil = 1;
-    ASR_UNSUPPORTED(a.Npad % 256 != 0, "asr_diag_pwconv_presplit: ceil128(n) must be a multiple of 256");
+    ASR_UNSUPPORTED(a.Npad % 256 != 0, "asr_diag_pwconv_presplit_8w: ceil128(n) must be a multiple of 256");
     a.tiles_n = (int)asr_cdiv(n, 256);
     const long long nwg = asr_cdiv(m, 256) * a.tiles_n;
     constexpr size_t lds = 2 * (256 * 128 + 2 * 4 * 256 * 16);
-    if (variant == 0) {
-        auto kern8 = pw_gemm_f16x3_pre_kernel<4, 2, 2, 4>;
-        static AsrDeviceOnce once;
-        ASR_HIP_CHECK(asr_allow_dynamic_lds(once, reinterpret_cast<const void*>(kern8), (int)lds));
-        hipLaunchKernelGGL(kern8, dim3((unsigned)nwg), dim3(512), lds, asr_stream(stream), a);
-    } else {
-        auto kern12 = pw_gemm_f16x3_pre_lw_kernel<16>;
-        static AsrDeviceOnce once;
-        ASR_HIP_CHECK(asr_allow_dynamic_lds(once, reinterpret_cast<const void*>(kern12), (int)lds));
-        hipLaunchKernelGGL(kern12, dim3((unsigned)nwg), dim3(768), lds, asr_stream(stream), a);
-    }
+    auto kern8 = pw_gemm_f16x3_pre_kernel<4, 2, 2, 4>;
+    static AsrDeviceOnce once;
+    ASR_HIP_CHECK(asr_allow_dynamic_lds(once, reinterpret_cast<const void*>(kern8), (int)lds));
+    hipLaunchKernelGGL(kern8, dim3((unsigned)nwg), dim3(512), lds, asr_stream(stream), a);
     ASR_LAUNCH_CHECK();
     return ASR_OK;
 }
