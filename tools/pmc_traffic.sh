@@ -9,6 +9,6 @@ mkdir -p "$out"
 out=$(cd "$out" && pwd)                     # absolute: the passes run from /tmp
 cd /tmp && export TMPDIR=/tmp
 for ctr in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d "$out/$ctr" -- python3 "$repo/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > "$out/$ctr.log" 2>&1
+  rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d "$out/$ctr" -- python3 "$repo/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-f32-line > "$out/$ctr.log" 2>&1
 done
 python3 "$repo/tools/pmc_summarize.py" "$out" > "$out/summary.json"
