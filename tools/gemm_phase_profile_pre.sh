@@ -6,7 +6,5 @@ set -e
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p gpurun_out
 lib=$(ASR_BUILD_VARIANT=phase python deeplabv3plus-augmented-superresolution_amd/csrc/build.py 2> gpurun_out/gemm_phase_build.log | tail -1)
-for lw in ${ASR_PHASE_VARIANTS:-0 1 2}; do
-  ASR_LIB=$lib ASR_PRE_LW=$lw python tools/bench_presplit.py > gpurun_out/gemm_phase_pre_lw$lw.log 2>&1
-  grep "\[phase-" gpurun_out/gemm_phase_pre_lw$lw.log | tac | awk '!seen[$1 $2 $3 $4 $5]++' | tac | cut -c1-420
-done
+ASR_LIB=$lib python tools/bench_presplit.py > gpurun_out/gemm_phase_pre.log 2>&1
+grep "\[phase-" gpurun_out/gemm_phase_pre.log | tac | awk '!seen[$1 $2 $3 $4 $5]++' | tac | cut -c1-420
