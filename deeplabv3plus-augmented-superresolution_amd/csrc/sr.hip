@@ -929,15 +929,10 @@ extern "C" int asr_sr_solve_cfg_f32(float* x, const float* y, const float* rot_t
     float* x_alt = resid + (size_t)batch * n * h * w;
     float* cur = x;
     float* nxt = x_alt;
-    // ASR_SR_FUSED_BWD=1: the one-kernel backward (what asr_sr_backward_* runs, which has no workspace) -- A/B timing
-    static const bool fused = getenv("ASR_SR_FUSED_BWD") && atoi(getenv("ASR_SR_FUSED_BWD")) != 0;
-    rc = prepare_backward(d);
-    if (rc != ASR_OK) return rc;
     float* const gr = x_alt + (size_t)batch * H * W;
-    const SrBwdKernel bwd_kernel = sr_backward_kernel_for(d.f);
     const SrGradTranslateKernel gr_kernel = sr_grad_translate_kernel_for(d.f);
     float* const xb = gr + (size_t)batch * n * sr_gr_plane_elems(H, W);   // bordered copy of the current x
-    if (!fused && num_iter > 0) {   // the borders stay zero for the whole solve; the interiors are rewritten every iteration
+    if (num_iter > 0) {   // the borders stay zero for the whole solve; the interiors are rewritten every iteration
         const size_t pe = sr_gr_plane_elems(H, W);
         ASR_HIP_CHECK(hipMemsetAsync(gr, 0, sizeof(float) * ((size_t)batch * n + batch) * pe, s));
         const size_t wp = (size_t)W + 2 * kGrPadX;
@@ -947,23 +942,16 @@ extern "C" int asr_sr_solve_cfg_f32(float* x, const float* y, const float* rot_t
                                            hipMemcpyDeviceToDevice, s));
     }
     for (int it = 0; it < num_iter; ++it) {
-        if (fused) hipLaunchKernelGGL(sr_forward_residual_kernel<false>, lr_grid(d), kBlock, 0, s, cur, y, rot_tf, trans_tf, resid, d);
-        else hipLaunchKernelGGL(sr_forward_residual_kernel<true>, lr_grid(d), kBlock, 0, s, xb, y, rot_tf, trans_tf, resid, d);
+        hipLaunchKernelGGL(sr_forward_residual_kernel<true>, lr_grid(d), kBlock, 0, s, xb, y, rot_tf, trans_tf, resid, d);
         ASR_LAUNCH_CHECK();
         if (last_loss_terms && it == num_iter - 1) {
             rc = asr_sr_loss_terms_cfg_f64(cur, resid, last_loss_terms, batch, n, H, W, h, w, cfg, stream);
             if (rc != ASR_OK) return rc;
         }
-        if (!fused) {
-            hipLaunchKernelGGL(gr_kernel, gr_grid(d), dim3(64, 4), 0, s, resid, inv_trans_tf, gr, d, 2.0f * lambda_df);
-            ASR_LAUNCH_CHECK();
-            hipLaunchKernelGGL(sr_backward_gather_kernel, gather_grid(d), dim3(64, 4), 0, s, cur, nxt, gr, inv_rot_tf, m, v, vhat,
-                               alphas + (size_t)it * batch, (float*)nullptr, d, lambda_tv, 2.0f * lambda_l2, lambda_l1, st, xb);
-        } else {
-            hipLaunchKernelGGL(bwd_kernel, bwd_grid(d), kBwdBlock, bwd_lds(d), s, cur, nxt, resid, inv_rot_tf, inv_trans_tf,
-                               m, v, vhat, alphas + (size_t)it * batch, (float*)nullptr, d, 2.0f * lambda_df, lambda_tv,
-                               2.0f * lambda_l2, lambda_l1, st);
-        }
+        hipLaunchKernelGGL(gr_kernel, gr_grid(d), dim3(64, 4), 0, s, resid, inv_trans_tf, gr, d, 2.0f * lambda_df);
+        ASR_LAUNCH_CHECK();
+        hipLaunchKernelGGL(sr_backward_gather_kernel, gather_grid(d), dim3(64, 4), 0, s, cur, nxt, gr, inv_rot_tf, m, v, vhat,
+                           alphas + (size_t)it * batch, (float*)nullptr, d, lambda_tv, 2.0f * lambda_l2, lambda_l1, st, xb);
         ASR_LAUNCH_CHECK();
         float* t = cur; cur = nxt; nxt = t;
     }

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""SR solver timing at the bench shape (N = 100 copies, 128^2 -> 512^2, 50 iterations).  ASR_SR_FUSED_BWD=1 selects the
-one-kernel backward; prints ms per solve and a checksum of the result (the two forms must print the same checksum)."""
+"""SR solver timing at the bench shape (N = 100 copies, 128^2 -> 512^2, 50 iterations): ms per solve and a checksum of the
+result."""
 import hashlib, os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -29,5 +29,5 @@ e0.record()
 for _ in range(5):
     x = solve()
 e1.record(); torch.cuda.synchronize()
-print(f"fused={os.environ.get('ASR_SR_FUSED_BWD', '0')}  {e0.elapsed_time(e1) / 5:.3f} ms per solve ({iters} iterations)  "
+print(f"{e0.elapsed_time(e1) / 5:.3f} ms per solve ({iters} iterations)  "
       f"sha1(x)={hashlib.sha1(x.cpu().numpy().tobytes()).hexdigest()[:16]}")
