@@ -897,6 +897,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void pw_gemm_f16x3_pre_kernel(PwAr
 }
 
 
+
 #endif  // ASR_DIAG_KERNELS
 
 // w [K][N] f32 -> two half planes [Kpad/8][Npad][8] (hi then lo), zero padded

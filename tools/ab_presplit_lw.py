@@ -18,9 +18,14 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from asr_amd import _lib, ops  # noqa: E402
 
 lib = _lib.load()
-fn_8w = lib.asr_diag_pwconv_presplit_8w
-fn_8w.restype = C.c_int
-fn_8w.argtypes = _lib.SIGNATURES["asr_pwconv_mfma_f16x3_presplit"][1]
+fns = [("8-wave (round 1)", lib.asr_diag_pwconv_presplit_8w)]
+if hasattr(lib, "asr_diag_pwconv_presplit_flags"):            # experiment kernels present in this diagnostic build
+    fns.append(("LDS progress counters", lib.asr_diag_pwconv_presplit_flags))
+for _n, _f in fns:
+    _f.restype = C.c_int
+    _f.argtypes = _lib.SIGNATURES["asr_pwconv_mfma_f16x3_presplit"][1]
+fns.append(("loader-wave (product)", lib.asr_pwconv_mfma_f16x3_presplit))
+NV = len(fns)
 dev = torch.device("cuda")
 torch.manual_seed(0)
 shapes = [(100, 32, 728, 728, False), (100, 32, 728, 728, True), (100, 32, 1536, 2048, False), (100, 32, 1024, 1536, False),
@@ -35,29 +40,29 @@ for b, hw, c, n, res in shapes:
     bias = torch.randn(n, device=dev)
     r = torch.randn(m, n, device=dev) if res else None
     xs, _, chunks = ops.dwconv3x3_split(x, wd, torch.zeros(c, device=dev))
-    outs = [torch.empty(m, n, device=dev) for _ in range(2)]
+    outs = [torch.full((m, n), float("nan"), device=dev) for _ in range(NV)]
     s = _lib.stream_ptr()
 
     def launch(which):
-        f = fn_8w if which == 0 else lib.asr_pwconv_mfma_f16x3_presplit
+        f = fns[which][1]
         _lib.check(f(_lib.ptr(xs), _lib.ptr(w16), _lib.ptr(bias), _lib.ptr(r, allow_none=True), _lib.ptr(outs[which]), m, c, n,
                      chunks, n, n if res else 0, 0, s), "presplit")
 
-    for _ in range(4):
-        launch(0)
-        launch(1)
+    for _ in range(3):
+        for which in range(NV):
+            launch(which)
     torch.cuda.synchronize()
-    ev = [[], []]
+    ev = [[] for _ in range(NV)]
     for _ in range(rounds):
-        for which in (0, 1):
+        for which in range(NV):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             launch(which)
             e1.record()
             ev[which].append((e0, e1))
     torch.cuda.synchronize()
-    t = [np.array([a.elapsed_time(b_) * 1e3 for a, b_ in ev[w]]) for w in (0, 1)]
-    same = bool(torch.equal(outs[0], outs[1]))
-    print(f"M={m} K={c} N={n} res={int(res)}: 8-wave (round 1) {np.median(t[0]):8.1f} us (min {t[0].min():.1f})   loader-wave (product) "
-          f"{np.median(t[1]):8.1f} us (min {t[1].min():.1f})   ratio {np.median(t[1]) / np.median(t[0]):.3f}   bit-identical {same}",
-          flush=True)
+    t = [np.array([a.elapsed_time(b_) * 1e3 for a, b_ in ev[w]]) for w in range(NV)]
+    same = all(bool(torch.equal(outs[0], outs[w])) for w in range(1, NV))
+    med = [float(np.median(v)) for v in t]
+    print(f"M={m} K={c} N={n} res={int(res)}: " + "   ".join(f"{fns[w][0]} {med[w]:8.1f} us" for w in range(NV)) +
+          "   ratios " + " ".join(f"{med[w] / med[0]:.3f}" for w in range(1, NV)) + f"   bit-identical {same}", flush=True)
