@@ -695,7 +695,11 @@ __global__ __launch_bounds__(768, 3) void pw_gemm_f16x3_pre_lw_kernel(PwArgs p) 
     }
 
     // ---- MFMA wave ------------------------------------------------------------------------------------------------
-    const int wm = wave / WN, wn = wave % WN;
+    // Waves w and w + 4 share a SIMD: they get the two column halves of the same row block, so that a padded last N-tile
+    // (N = 728: 2 of the 8 column tiles of the right half are pure padding, and are skipped) shortens every SIMD's K-step alike.
+    const int wm = wave & 3, wn = wave >> 2;
+    const int wave_e = wm * WN + wn;                           // the epilogue's (row block, column half) numbering
+    const int ct_valid = min(CT, max(0, (p.N - (tile_n * BN + wn * (CT * 16)) + 15) >> 4));   // column tiles holding real columns
     const int l16 = lane & 15, oct = lane >> 4;                // A: row = l16, k = 8 oct ..; B: column = l16, same k
     f32x4 acc[RT][CT];
 #pragma unroll
@@ -714,59 +718,66 @@ __global__ __launch_bounds__(768, 3) void pw_gemm_f16x3_pre_lw_kernel(PwArgs p) 
 #ifdef ASR_GEMM_PHASE_PROFILE
     const long long loop_c0 = (long long)__builtin_readcyclecounter(), loop_r0 = (long long)__builtin_amdgcn_s_memrealtime();
 #endif
-    for (int kt = 0; kt < KT; ++kt) {
-        const char* const st = lds + (kt & 1) * STAGE_BYTES;
-        // 2 halves x 8 column tiles = 16 groups of 6 MFMAs; the fragments of group g + 1 are requested before the MFMAs of
-        // group g (one B double buffer, the A pair of the second half is requested under the last group of the first),
-        // and a scheduling barrier per group keeps the compiler from hoisting every read to the top (it would need 160
-        // fragment registers and spill).
-        f16x8 ah[2], al[2], bh[2], bl[2];
-        auto read_a = [&](int half, int i) {                   // hi / lo fragments of row tile 2 * half + i
-            const int row = (wm * RT + 2 * half + i) * 16 + l16, swz = (row >> 1) & 7;
-            ah[i] = *reinterpret_cast<const f16x8*>(st + row * 128 + ((oct ^ swz) << 4));
-            al[i] = *reinterpret_cast<const f16x8*>(st + row * 128 + (((4 + oct) ^ swz) << 4));
-        };
-        auto read_b = [&](int j, int buf) {
-            const int col = (wn * CT + j) * 16 + l16;
-            bh[buf] = *reinterpret_cast<const f16x8*>(st + A_BYTES + (oct * BN + col) * 16);
-            bl[buf] = *reinterpret_cast<const f16x8*>(st + A_BYTES + B_BYTES + (oct * BN + col) * 16);
-        };
-        read_a(0, 0);
-        read_a(0, 1);
-        read_b(0, 0);
-        auto group = [&](auto G) {
-            constexpr int g = decltype(G)::value, half = g / CT, j = g % CT;
-            constexpr bool last_of_half0 = g == CT - 1;
-            if (g + 1 < 2 * CT) read_b((g + 1) % CT, (g + 1) & 1);
+    auto kloop = [&](auto CTV_) {
+        constexpr int CTV = decltype(CTV_)::value;             // column tiles computed by this wave (even; 8 = all)
+        for (int kt = 0; kt < KT; ++kt) {
+            const char* const st = lds + (kt & 1) * STAGE_BYTES;
+            // 2 halves x CTV column tiles = 2 CTV groups of 6 MFMAs (16 groups for a full tile); the fragments of group g + 1 are requested before the MFMAs of
+            // group g (one B double buffer, the A pair of the second half is requested under the last group of the first),
+            // and a scheduling barrier per group keeps the compiler from hoisting every read to the top (it would need 160
+            // fragment registers and spill).
+            f16x8 ah[2], al[2], bh[2], bl[2];
+            auto read_a = [&](int half, int i) {                   // hi / lo fragments of row tile 2 * half + i
+                const int row = (wm * RT + 2 * half + i) * 16 + l16, swz = (row >> 1) & 7;
+                ah[i] = *reinterpret_cast<const f16x8*>(st + row * 128 + ((oct ^ swz) << 4));
+                al[i] = *reinterpret_cast<const f16x8*>(st + row * 128 + (((4 + oct) ^ swz) << 4));
+            };
+            auto read_b = [&](int j, int buf) {
+                const int col = (wn * CT + j) * 16 + l16;
+                bh[buf] = *reinterpret_cast<const f16x8*>(st + A_BYTES + (oct * BN + col) * 16);
+                bl[buf] = *reinterpret_cast<const f16x8*>(st + A_BYTES + B_BYTES + (oct * BN + col) * 16);
+            };
+            read_a(0, 0);
+            read_a(0, 1);
+            read_b(0, 0);
+            auto group = [&](auto G) {
+                constexpr int g = decltype(G)::value, half = g / CTV, j = g % CTV;
+                constexpr bool last_of_half0 = g == CTV - 1;
+                if (g + 1 < 2 * CTV) read_b((g + 1) % CTV, (g + 1) & 1);
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                f32x4& a4 = acc[2 * half + i][j];
-                a4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh[g & 1], a4, 0, 0, 0);
-                a4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl[g & 1], a4, 0, 0, 0);
-                a4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bh[g & 1], a4, 0, 0, 0);
-                if (last_of_half0) read_a(1, i);               // the second half's row tile into the registers just consumed
-            }
-            // order inside the group: the next group's fragment reads first, then the MFMAs (the A refills behind their rows)
-            if (g + 1 < 2 * CT) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
-            if (last_of_half0) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
-            if (last_of_half0) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        };
-        asr_static_for<2 * CT>(group);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // this wave's reads of the stage are done
-        PHASE_MARK(2);
-        __builtin_amdgcn_s_barrier();
-        PHASE_MARK(6);
-    }
+                for (int i = 0; i < 2; ++i) {
+                    f32x4& a4 = acc[2 * half + i][j];
+                    a4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh[g & 1], a4, 0, 0, 0);
+                    a4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl[g & 1], a4, 0, 0, 0);
+                    a4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bh[g & 1], a4, 0, 0, 0);
+                    if (last_of_half0) read_a(1, i);               // the second half's row tile into the registers just consumed
+                }
+                // order inside the group: the next group's fragment reads first, then the MFMAs (the A refills behind their rows)
+                if (g + 1 < 2 * CTV) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+                if (last_of_half0) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+                if (last_of_half0) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            asr_static_for<2 * CTV>(group);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // this wave's reads of the stage are done
+            PHASE_MARK(2);
+            __builtin_amdgcn_s_barrier();
+            PHASE_MARK(6);
+        }
+    };
+    if (ct_valid > 6) kloop(std::integral_constant<int, 8>{});
+    else if (ct_valid > 4) kloop(std::integral_constant<int, 6>{});
+    else if (ct_valid > 2) kloop(std::integral_constant<int, 4>{});
+    else kloop(std::integral_constant<int, 2>{});
 #ifdef ASR_GEMM_PHASE_PROFILE
     if (tid == 0 && orig < ASR_PHASE_BLOCKS) {
         g_phase_cycles[orig * 16 + 11] = (long long)__builtin_readcyclecounter() - loop_c0;
         g_phase_cycles[orig * 16 + 12] = (long long)__builtin_amdgcn_s_memrealtime() - loop_r0;
     }
 #endif
-    pw_epilogue16<4, WN, RT, CT, 4>(p, acc, smem, tile_m, tile_n, wave, lane);
+    pw_epilogue16<4, WN, RT, CT, 4>(p, acc, smem, tile_m, tile_n, wave_e, lane);
 #ifdef ASR_GEMM_PHASE_PROFILE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     PHASE_MARK(7);
@@ -895,6 +906,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void pw_gemm_f16x3_pre_kernel(PwAr
         for (int i = 0; i < 8; ++i) g_phase_cycles[orig * 16 + i] = ph[i];
 #endif
 }
+
 
 
 

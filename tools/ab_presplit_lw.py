@@ -19,8 +19,9 @@ from asr_amd import _lib, ops  # noqa: E402
 
 lib = _lib.load()
 fns = [("8-wave (round 1)", lib.asr_diag_pwconv_presplit_8w)]
-if hasattr(lib, "asr_diag_pwconv_presplit_flags"):            # experiment kernels present in this diagnostic build
-    fns.append(("LDS progress counters", lib.asr_diag_pwconv_presplit_flags))
+for _sym, _label in (("asr_diag_pwconv_presplit_exp", "experiment"),):      # experiment kernels, if this diagnostic build has any
+    if hasattr(lib, _sym):
+        fns.append((_label, getattr(lib, _sym)))
 for _n, _f in fns:
     _f.restype = C.c_int
     _f.argtypes = _lib.SIGNATURES["asr_pwconv_mfma_f16x3_presplit"][1]
