@@ -436,6 +436,41 @@ __global__ __launch_bounds__(256) void resize_bilinear_kernel(const float* __res
     *reinterpret_cast<f32x4*>(y + ((b * h_out + oy) * w_out + ox) * ldy + c4 * 4) = top + (bot - top) * ty;
 }
 
+// 4x horizontal upsampling (the decoder's Resizing 32 -> 128, model.py:241-242): the four outputs 4k .. 4k + 3 read input
+// columns k - 1, k, k + 1 only, so a thread produces all four from 6 loads instead of 16 -- the L1 / texture-address path,
+// not HBM, bounded the one-output-per-thread form (1.68 GB written at 3 TB/s).  Same expressions per output -> bit-identical.
+__global__ __launch_bounds__(256) void resize_bilinear_x4_kernel(const float* __restrict__ x, float* __restrict__ y, int h_in,
+                                                                 int w_in, int c, int h_out, int ldx, int ldy, float scale_y) {
+    const unsigned c4n = (unsigned)c >> 2;
+    const unsigned idx = blockIdx.x * 256u + threadIdx.x;
+    const unsigned k = idx / c4n, c4 = idx - k * c4n;
+    if (k >= (unsigned)w_in) return;
+    const int oy = blockIdx.y;
+    const long long b = blockIdx.z;
+    const float py = ((float)oy + 0.5f) * scale_y - 0.5f;
+    const float fy = floorf(py);
+    const int ylo = max((int)fy, 0), yhi = min((int)ceilf(py), h_in - 1);
+    const float ty = py - fy;
+    const int cm = max((int)k - 1, 0), cp = min((int)k + 1, w_in - 1);
+    const float* base = x + b * h_in * w_in * ldx + c4 * 4;
+    const float* rlo = base + (long long)ylo * w_in * ldx;
+    const float* rhi = base + (long long)yhi * w_in * ldx;
+    const f32x4 tA = *reinterpret_cast<const f32x4*>(rlo + (long long)cm * ldx), tB = *reinterpret_cast<const f32x4*>(rlo + (long long)k * ldx),
+                tC = *reinterpret_cast<const f32x4*>(rlo + (long long)cp * ldx);
+    const f32x4 bA = *reinterpret_cast<const f32x4*>(rhi + (long long)cm * ldx), bB = *reinterpret_cast<const f32x4*>(rhi + (long long)k * ldx),
+                bC = *reinterpret_cast<const f32x4*>(rhi + (long long)cp * ldx);
+    float* out = y + ((b * h_out + oy) * (long long)(4 * w_in) + 4 * k) * ldy + c4 * 4;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const float px = ((float)(4 * k + t) + 0.5f) * 0.25f - 0.5f;      // the generic kernel's expression with scale_x = 0.25
+        const float tx = px - floorf(px);
+        const f32x4 tl = t < 2 ? tA : tB, tr = t < 2 ? tB : tC, bl = t < 2 ? bA : bB, br = t < 2 ? bB : bC;
+        const f32x4 top = tl + (tr - tl) * tx;
+        const f32x4 bot = bl + (br - bl) * tx;
+        *reinterpret_cast<f32x4*>(out + (long long)t * ldy) = top + (bot - top) * ty;
+    }
+}
+
 // Standard-output mask (generate_standard_output.py:52-65 with the model's final Resizing, model.py:108-111): bilinear
 // upsample of one logits map (half-pixel, the arithmetic of resize_bilinear_kernel), argmax over the classes (first
 // maximum), keep class_id else 0 -- one pass, the upsampled logits never exist.
@@ -554,6 +589,12 @@ extern "C" int asr_resize_bilinear_f32(const float* x, float* y, int batch, int 
                     "asr_resize_bilinear_f32: c, ldx, ldy multiples of 4 and 16-byte aligned pointers required");
     const float sy = (float)h_in / (float)h_out, sx = (float)w_in / (float)w_out;
     ASR_UNSUPPORTED(batch > 65535 || h_out > 65535, "asr_resize_bilinear_f32: batch and h_out must not exceed 65535 (grid dimensions)");
+    if (w_out == 4 * w_in && w_in >= 2) {
+        hipLaunchKernelGGL(resize_bilinear_x4_kernel, dim3((unsigned)asr_cdiv((long long)w_in * (c >> 2), 256), (unsigned)h_out, (unsigned)batch),
+                           dim3(256), 0, asr_stream(stream), x, y, h_in, w_in, c, h_out, ldx, ldy, sy);
+        ASR_LAUNCH_CHECK();
+        return ASR_OK;
+    }
     hipLaunchKernelGGL(resize_bilinear_kernel, dim3((unsigned)asr_cdiv((long long)w_out * (c >> 2), 256), (unsigned)h_out, (unsigned)batch),
                        dim3(256), 0, asr_stream(stream), x, y, batch, h_in, w_in, c, h_out, w_out, ldx, ldy, sy, sx);
     ASR_LAUNCH_CHECK();

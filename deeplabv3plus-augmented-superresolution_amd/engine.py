@@ -602,6 +602,11 @@ class DeeplabEngine:
                     print(f"asr_amd: {layer} runs on the exact-f32 MFMA kernel ({why})", file=sys.stderr)
         return moved
 
+    def input_view(self, B, H, Wd, lane=0):
+        """The plan's own input buffer as a [B,H,W,3] tensor: a producer (the augmentation kernel) that writes here saves
+        forward() its copy of the batch.  Valid until the next forward of the same (shape, lane)."""
+        return self.plan(B, H, Wd, lane)["x_in"].t.view(B, H, Wd, 3)
+
     def forward(self, x_dev, profile=None, lane=0):
         """x_dev: [B,H,W,3] float32 device tensor -> logits [B,H/4,W/4,classes] (a view of plan
         memory: consume or clone it before the next forward of the same shape).
@@ -610,7 +615,8 @@ class DeeplabEngine:
         assert c == 3
         plan = self.plan(B, H, Wd, lane)
         xin = plan["x_in"].t
-        xin.copy_(x_dev.reshape(-1))
+        if x_dev.data_ptr() != xin.data_ptr():          # (input_view: already in place)
+            xin.copy_(x_dev.reshape(-1))
         lib = _lib.load()
         s = _lib.stream_ptr()
         if profile is None:

@@ -109,9 +109,11 @@ class DeeplabModel:
         self.precision = self.engine.precision
         self.device = self.engine.device
 
-    def predict_device(self, x, batch_size=16, profile=None, lane=0):
+    def predict_device(self, x, batch_size=16, profile=None, lane=0, clone=True):
         """x: [N,H,W,3] float32 (host array or device tensor) -> device tensor [N,h,w,classes].
-        lane: activation pool to use (forward passes running concurrently on different streams need different lanes)."""
+        lane: activation pool to use (forward passes running concurrently on different streams need different lanes).
+        clone=False (single-batch calls only): return the plan's own logits buffer instead of a copy -- valid until the next
+        forward of the same (shape, lane)."""
         if not isinstance(x, torch.Tensor):
             x = torch.as_tensor(np.ascontiguousarray(x, dtype=np.float32))
         n, h, w, c = x.shape
@@ -126,7 +128,7 @@ class DeeplabModel:
             logits = self.engine.forward(xb, profile=profile, lane=lane)
             if self.final_upsample:
                 logits = self._upsample(logits, (h, w))
-            else:
+            elif clone or n > batch_size:
                 logits = logits.clone()
             outs.append(logits)
         out = outs[0] if len(outs) == 1 else torch.cat(outs, dim=0)

@@ -62,13 +62,17 @@ def warp_affine(src, transforms, out_hw=None, n=None, interpolation="bilinear"):
     return dst
 
 
-def augment_copies(image, rot_tf, trans_tf):
-    """image [H,W,C] -> [N,H,W,C] = translate(rotate(tile(image)))."""
+def augment_copies(image, rot_tf, trans_tf, out=None):
+    """image [H,W,C] -> [N,H,W,C] = translate(rotate(tile(image))); out: an [N,H,W,C] tensor to write into (e.g. the input
+    buffer of a forward plan)."""
     h, w, c = image.shape
     n = rot_tf.shape[0]
     if rot_tf.shape != (n, 8) or trans_tf.shape != (n, 8):
         raise AsrError("augment_copies: transforms must be [N,8]")
-    out = torch.empty((n, h, w, c), dtype=f32, device=image.device)
+    if out is None:
+        out = torch.empty((n, h, w, c), dtype=f32, device=image.device)
+    elif tuple(out.shape) != (n, h, w, c):
+        raise AsrError(f"augment_copies: out must be [{n},{h},{w},{c}], got {tuple(out.shape)}")
     call("asr_augment_copies_f32", ptr(image), ptr(out), ptr(rot_tf), ptr(trans_tf), n, h, w, c, stream_ptr())
     return out
 

@@ -43,8 +43,14 @@ class HotPath:
     # ---- stage 1 (model stream): augment -> forward -> OPM (-> standard mask) --------------------------
     def _stage_model(self, image_dev, angles, shifts, profile=None, want_standard=True, lane=0):
         out_hw = self.sr.output_size
-        copies = au.augment_on_device(image_dev, angles, shifts)
-        preds = self.model.predict_device(copies, batch_size=self.batch_size, profile=profile, lane=lane)
+        n = len(angles)
+        h, w, _ = image_dev.shape
+        if n <= self.batch_size:      # one forward pass: the copies are written straight into the plan's input buffer, the
+            copies = au.augment_on_device(image_dev, angles, shifts, out=self.model.engine.input_view(n, h, w, lane))
+            preds = self.model.predict_device(copies, batch_size=n, profile=profile, lane=lane, clone=False)   # logits stay there
+        else:
+            copies = au.augment_on_device(image_dev, angles, shifts)
+            preds = self.model.predict_device(copies, batch_size=self.batch_size, profile=profile, lane=lane)
         del copies
         cls, mx = au.output_processing(preds, self.class_id, self.mode)
         # the image's masks live in one [4, H, W] int32 buffer (rows MASK_KEYS): the IoU kernel reads it as it stands

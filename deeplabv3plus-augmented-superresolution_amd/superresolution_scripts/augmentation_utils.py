@@ -29,12 +29,12 @@ def draw_augmentation_parameters(num_aug, angle_max, shift_max):
     return angles.astype("float32"), shifts.astype("float32")
 
 
-def augment_on_device(image_dev, angles, shifts):
-    """image_dev [H,W,C] device tensor -> [N,H,W,C] device tensor."""
+def augment_on_device(image_dev, angles, shifts, out=None):
+    """image_dev [H,W,C] device tensor -> [N,H,W,C] device tensor (written into ``out`` when given)."""
     h, w, _ = image_dev.shape
     rot = ops.to_device(T.rotation_transforms(angles, h, w), device=image_dev.device)
     tr = ops.to_device(T.translation_transforms(shifts), device=image_dev.device)
-    return ops.augment_copies(image_dev.contiguous(), rot, tr)
+    return ops.augment_copies(image_dev.contiguous(), rot, tr, out=out)
 
 
 def _image_to_device(image):

@@ -276,7 +276,14 @@ def test_gap_and_resize(dev):
     y = _rand(rng, 2, 8, 8, 256)
     ref = tf_ops.resize_bilinear(torch.from_numpy(y), (32, 32)).numpy()
     got = ops.resize_bilinear(ops.to_device(y), (32, 32)).cpu().numpy()
-    np.testing.assert_allclose(got, ref, rtol=0, atol=1e-6)
+    np.testing.assert_allclose(got, ref, rtol=0, atol=1e-6)   # 4x in width: the three-column kernel
+    for hw in ((24, 24), (16, 32), (20, 12)):                   # generic kernel (3x, 2.5x / 1.5x), 4x in width with 2x in height
+        ref = tf_ops.resize_bilinear(torch.from_numpy(y), hw).numpy()
+        got = ops.resize_bilinear(ops.to_device(y), hw).cpu().numpy()
+        np.testing.assert_allclose(got, ref, rtol=0, atol=3e-6)   # (non-integer ratios: the lerp weights round differently)
+    wide = torch.zeros((2, 32, 32, 320), device=dev)            # into a channel slice of a concat buffer (ldy > c)
+    ops.resize_bilinear(ops.to_device(y), (32, 32), out=wide, ldy=320)
+    assert torch.equal(wide[..., :256], ops.resize_bilinear(ops.to_device(y), (32, 32))) and float(wide[..., 256:].abs().max()) == 0.0
     one = _rand(rng, 2, 1, 1, 256)               # image-pooling broadcast (model.py:204-205)
     got = ops.resize_bilinear(ops.to_device(one), (16, 16)).cpu().numpy()
     assert np.array_equal(got, np.broadcast_to(one, (2, 16, 16, 256)))
@@ -285,10 +292,10 @@ def test_gap_and_resize(dev):
 @pytest.mark.parametrize("c,n,hw,stride,rate", [(728, 728, 32, 1, 1), (256, 256, 32, 2, 1), (96, 256, 16, 1, 2), (1536, 2048, 16, 1, 2)])
 def test_presplit_sepconv_matches_the_f32_handoff(dev, c, n, hw, stride, rate):
     """dw -> split-f16 chunks -> LDS-DMA GEMM (256 x 256 tile) against dw -> f32 -> split-f16 GEMM: the same hi / lo halves
-    enter the same three products.  With ASR_PRE_MFMA=32 (v_mfma_f32_32x32x16_f16, the in-kernel-split kernel's shape and
-    k order) the outputs are bitwise equal; the default v_mfma_f32_16x16x32_f16 form sums each 32-deep K-step in one MFMA,
-    so it differs by f32 summation-order noise only: both must sit within 4e-6 * sum |x||w| of the float64 product
-    (the bound of test_pwconv_split_f16_is_f32_grade).  Tails: M, K and N not multiples of the tile."""
+    enter the same three products.  The 256 x 256 kernel's v_mfma_f32_16x16x32_f16 sums each 32-deep K-step in one MFMA (the
+    in-kernel-split kernel uses two v_mfma_f32_32x32x16_f16), so the two differ by f32 summation-order noise only: both must
+    sit within 4e-6 * sum |x||w| of the float64 product (the bound of test_pwconv_split_f16_is_f32_grade).  Tails: M, K and N
+    not multiples of the tile (N = 728: the last N-tile's padded column tiles are skipped)."""
     from asr_amd import ops
     rng = np.random.default_rng(61)
     b = 3
@@ -309,8 +316,6 @@ def test_presplit_sepconv_matches_the_f32_handoff(dev, c, n, hw, stride, rate):
     xs, (bb, ho, wo), chunks = ops.dwconv3x3_split(x, wd, bd, stride=stride, rate=rate, pre_relu=True, post_relu=0)
     assert bb * ho * wo == m and chunks == (c + 31) // 32
     got = ops.pwconv_presplit(xs, w16, bk, c, n, chunks, residual=res, relu=1)
-    if os.environ.get("ASR_PRE_MFMA") == "32":
-        assert torch.equal(got, ref)
     a64 = ref_dw.reshape(m, c).cpu().numpy().astype(np.float64)
     exact = np.maximum(a64 @ wk_h.astype(np.float64) + bk_h, 0) + res_h
     bound = np.abs(a64) @ np.abs(wk_h).astype(np.float64) + np.abs(bk_h) + np.abs(res_h)
