@@ -1,5 +1,5 @@
 """Full-size parity against the oracle at the shapes bench.py times (BASELINE configs[1]: 512x512 images,
-num_aug=100, 128x128 features, argmax OPM, class 8), through ``HotPath``'s own stages:
+num_aug=100, 128x128 features, argmax OPM, class 8; configs[2]: the float OPM maps), through ``HotPath``'s own stages:
 
   * augment: all 100 copies are produced by the HIP kernel; 4 of them (first, second, a middle one, last) are compared
     with the oracle's tile -> rotate -> translate (augmentation_utils.py:11-27);
@@ -57,22 +57,40 @@ def problem(dev):
     copies = au.augment_on_device(img_dev, angles, shifts)
     logits = model.predict_device(copies, batch_size=N)
     masks, _ = au.output_processing(logits, CLS, "argmax")
+    # configs[2]: the per-class float map path -- last_activation="softmax" (model.py:124-125) + "slice" OPM, and the
+    # "slice_max" OPM on the raw logits -- on the same 100 copies
+    model.last_activation = "softmax"
+    probs = model.predict_device(copies, batch_size=N)
+    model.last_activation = None
+    slice_sm, _ = au.output_processing(probs, CLS, "slice")
+    smax_cls, smax_max = au.output_processing(logits, CLS, "slice_max")
     torch.cuda.synchronize()
+    idx = list(SAMPLE)
     out = dict(weights=weights, img=img, angles=angles, shifts=shifts, model=model,
-               copies=copies[list(SAMPLE)].cpu().numpy(), logits=logits[list(SAMPLE)].cpu().numpy(),
-               masks=masks.cpu().numpy())
-    del copies, logits
+               copies=copies[idx].cpu().numpy(), logits=logits[idx].cpu().numpy(), masks=masks.cpu().numpy(),
+               probs=probs[idx].cpu().numpy(), slice_sm=slice_sm[idx].cpu().numpy(), smax_cls=smax_cls[idx].cpu().numpy(),
+               smax_max=smax_max[idx].cpu().numpy())
+    del copies, logits, probs
     return out
 
 
-def test_augment_forward_opm_at_full_size(problem):
+@pytest.fixture(scope="module")
+def oracle_side(problem):
+    """The oracle's copies and logits of the 4 sampled copies (~10 s of CPU time, shared by the tests below)."""
     p = problem
     idx = list(SAMPLE)
     tiled = torch.from_numpy(np.broadcast_to(p["img"][None], (len(idx), H, W, 3)).copy())
     o_copies = tf_ops.translate(tf_ops.rotate(tiled, p["angles"][idx]), p["shifts"][idx]).numpy()
+    o_logits = OracleDeeplabV3Plus(p["weights"]).predict(o_copies, batch_size=len(idx))
+    return dict(copies=o_copies, logits=o_logits)
+
+
+def test_augment_forward_opm_at_full_size(problem, oracle_side):
+    p = problem
+    idx = list(SAMPLE)
+    o_copies, o_logits = oracle_side["copies"], oracle_side["logits"]
     assert np.array_equal(p["copies"][0], p["img"])                       # copy 0 is the image itself
     np.testing.assert_allclose(p["copies"], o_copies, rtol=0, atol=2e-6)
-    o_logits = OracleDeeplabV3Plus(p["weights"]).predict(o_copies, batch_size=len(idx))
     assert o_logits.shape == p["logits"].shape == (len(idx), h, w, 21)
     np.testing.assert_allclose(p["logits"], o_logits, rtol=0, atol=2e-4 * np.abs(o_logits).max())
     o_masks, _ = o_aug.opm(o_logits, CLS, "argmax")
@@ -80,6 +98,27 @@ def test_augment_forward_opm_at_full_size(problem):
     frac = float((o_masks == CLS).mean())
     assert 0.05 < frac < 0.8, frac                                        # a real class-8 region
     agree = float((p["masks"][idx] == o_masks).mean())
+    assert agree >= 0.999, agree
+
+
+def test_float_opm_maps_at_full_size(problem, oracle_side):
+    """BASELINE configs[2] at full size: softmax + "slice" (each copy's class-8 probability min-max-normalised by that
+    prediction's own global min / max, augmentation_utils.py:95-104) and "slice_max" (class logit + max of the other 20,
+    :82-93) against the oracle on the sampled copies."""
+    p = problem
+    o_logits = oracle_side["logits"]
+    o_probs = torch.softmax(torch.from_numpy(o_logits), dim=-1).numpy()
+    np.testing.assert_allclose(p["probs"], o_probs, rtol=0, atol=2e-5)
+    o_slice, _ = o_aug.opm(o_probs, CLS, "slice")
+    o_slice = np.stack(o_slice)[..., 0]
+    assert o_slice.max() - o_slice.min() > 0.5                            # a dense float map with structure, not a constant
+    np.testing.assert_allclose(p["slice_sm"], o_slice, rtol=0, atol=5e-5)
+    o_cls, o_max = o_aug.opm(o_logits, CLS, "slice_max")
+    scale = np.abs(o_logits).max()
+    np.testing.assert_allclose(p["smax_cls"], np.stack(o_cls)[..., 0], rtol=0, atol=2e-4 * scale)
+    np.testing.assert_allclose(p["smax_max"], np.stack(o_max)[..., 0], rtol=0, atol=2e-4 * scale)
+    # the decision compute_SR takes from the two maps (class >= max of the others, superres_utils.py:253-256), per pixel
+    agree = float(((p["smax_cls"] >= p["smax_max"]) == (np.stack(o_cls)[..., 0] >= np.stack(o_max)[..., 0])).mean())
     assert agree >= 0.999, agree
 
 
