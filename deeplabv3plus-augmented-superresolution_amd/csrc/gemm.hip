@@ -628,7 +628,12 @@ __device__ __forceinline__ void asr_static_for(F& f) {
     asr_static_for_impl(f, std::make_integer_sequence<int, N>{});
 }
 
-template <int PIECES_PER_LOADER = 16>
+// MOCK_FUSED (diagnostic library only, tools/ab_presplit_lw.py "experiment"): the four loader waves behave like the producer
+// waves of a fused depthwise -> pointwise layer WOULD -- per K-step each requests 8 B pieces by LDS-DMA, loads its share of
+// the 40 KB of f32 input rows (8 image rows + 2 halo rows of a 32-wide map, 32 channels) into registers two K-steps ahead,
+// issues 416 VALU instructions on them and writes its 8 KB of the A stage with ds_write_b128.  The A stage then holds
+// garbage: TIMING ONLY, an upper bound on what the fusion could reach.
+template <int PIECES_PER_LOADER = 16, bool MOCK_FUSED = false>
 __global__ __launch_bounds__(768, 3) void pw_gemm_f16x3_pre_lw_kernel(PwArgs p) {
     constexpr int BM = 256, BN = 256, WN = 2, RT = 4, CT = 8;
     constexpr int A_BYTES = BM * 128, B_BYTES = 4 * BN * 16, STAGE_BYTES = A_BYTES + 2 * B_BYTES;
@@ -644,6 +649,69 @@ __global__ __launch_bounds__(768, 3) void pw_gemm_f16x3_pre_lw_kernel(PwArgs p) 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int KT = p.Kpad / BK;
 
+#ifdef ASR_DIAG_KERNELS
+    if (MOCK_FUSED && wave >= 8) {
+        const int w = wave - 8;
+        const long long plane_bytes = (long long)p.Kpad * p.Npad * 2;
+        const char* bsrc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int qb = (w * 8 + j) * 64 + lane, plane = qb >> 10, r = qb & 1023, oct = r >> 8, col = r & 255;
+            bsrc[j] = reinterpret_cast<const char*>(p.wp) + plane * plane_bytes + (((long long)oct * p.Npad) + (long long)tile_n * BN + col) * 16;
+        }
+        const char* rsrc[10];
+#pragma unroll
+        for (int r = 0; r < 10; ++r) {
+            long long px = (long long)tile_m * BM - 32 + w * 80 + r * 8 + (lane >> 3);
+            px = px < 0 ? 0 : (px >= p.M ? p.M - 1 : px);
+            rsrc[r] = reinterpret_cast<const char*>(p.x) + (px * p.ldx) * 128 + (lane & 7) * 16;
+        }
+        auto issue_b = [&](int kt, int stage) {
+            char* const st = lds + stage * STAGE_BYTES + A_BYTES + w * 8 * 1024;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) glds16(bsrc[j] + (long long)kt * 4 * p.Npad * 16, st + j * 1024);
+        };
+        f32x4 rows[2][10];
+        auto load_rows = [&](int kt, int buf) {
+#pragma unroll
+            for (int r = 0; r < 10; ++r) rows[buf][r] = *reinterpret_cast<const f32x4*>(rsrc[r] + (long long)(kt < KT ? kt : KT - 1) * 128);
+        };
+        auto produce = [&](int stage, int buf) {                // 416 VALU instructions on the rows, then 8 x ds_write_b128
+#pragma unroll
+            for (int it = 0; it < 13; ++it)
+#pragma unroll
+                for (int r = 0; r < 8; ++r)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(rows[buf][r][e]) : "v"(rows[buf][(r + 1) % 10][e]), "v"(rows[buf][9][(e + 1) & 3]));
+            char* const st = lds + stage * STAGE_BYTES + w * 8 * 1024 + lane * 16;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) *reinterpret_cast<f32x4*>(st + j * 1024) = rows[buf][j];
+        };
+        issue_b(0, 0);
+        load_rows(0, 0);
+        load_rows(1, 1);
+        asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        produce(0, 0);
+        asm volatile("s_waitcnt vmcnt(10)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        for (int kt = 0; kt < KT; kt += 2) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {                       // K-step kt + h: produce the stage of kt + h + 1 from rows[(h + 1) & 1]
+                const int k = kt + h;
+                if (k < KT) {
+                    if (k + 1 < KT) issue_b(k + 1, (k + 1) & 1);
+                    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");       // the rows of k + 1 (requested a K-step ago) are in
+                    if (k + 1 < KT) produce((k + 1) & 1, (h + 1) & 1);
+                    load_rows(k + 2, h & 1);                                 // two K-steps ahead, into the buffer just consumed
+                    asm volatile("s_waitcnt vmcnt(10)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");   // B pieces landed, A stores done
+                    __builtin_amdgcn_s_barrier();
+                }
+            }
+        }
+        return;
+    }
+#endif
     if (wave >= 8) {
         // ---- loader wave: pieces (wave - 8) * 16 .. + 15 of every stage ------------------------------------------
         const int first = (wave - 8) * PIECES_PER_LOADER;
@@ -1191,6 +1259,28 @@ extern "C" int asr_conv3x3_mfma_f16x3(const float* x, const float* w_packed, con
 }
 
 #ifdef ASR_DIAG_KERNELS
+// timing-only mock of a fused depthwise -> pointwise layer (pw_gemm_f16x3_pre_lw_kernel<16, true>); results are garbage
+extern "C" int asr_diag_pwconv_presplit_exp(const void* x_split, const float* w_packed, const float* bias, const float* residual,
+                                            float* y, int64_t m, int k, int n, int ldx_chunks, int ldy, int ldres, int relu,
+                                            asr_stream_t stream) {
+    ASR_REQUIRE(x_split && w_packed && y && m > 0 && k > 0 && n > 0, "asr_diag_pwconv_presplit_exp: bad arguments");
+    PwArgs a{};
+    a.x = reinterpret_cast<const float*>(x_split); a.wp = w_packed; a.bias = bias; a.res = residual; a.y = y;
+    a.M = m; a.K = k; a.N = n; a.Npad = round_up(n, 128); a.Kpad = round_up(k, BK);
+    a.ldx = ldx_chunks; a.ldy = ldy; a.ldres = ldres; a.relu = relu;
+    a.taps = 1; a.cin = k; a.stride = 1; a.pad = 0; a.dil = 1;
+    ASR_UNSUPPORTED(a.Npad % 256 != 0, "asr_diag_pwconv_presplit_exp: ceil128(n) must be a multiple of 256");
+    a.tiles_n = (int)asr_cdiv(n, 256);
+    const long long nwg = asr_cdiv(m, 256) * a.tiles_n;
+    constexpr size_t lds = 2 * (256 * 128 + 2 * 4 * 256 * 16);
+    auto kern = pw_gemm_f16x3_pre_lw_kernel<16, true>;
+    static AsrDeviceOnce once;
+    ASR_HIP_CHECK(asr_allow_dynamic_lds(once, reinterpret_cast<const void*>(kern), (int)lds));
+    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(768), lds, asr_stream(stream), a);
+    ASR_LAUNCH_CHECK();
+    return ASR_OK;
+}
+
 // asr_pwconv_mfma_f16x3_presplit's arguments on round 1's 8-wave kernel (diagnostic library only; not in include/asr_hip.h)
 extern "C" int asr_diag_pwconv_presplit_8w(const void* x_split, const float* w_packed, const float* bias, const float* residual,
                                            float* y, int64_t m, int k, int n, int ldx_chunks, int ldy, int ldres, int relu,
