@@ -19,7 +19,7 @@ from asr_amd import _lib, ops  # noqa: E402
 
 lib = _lib.load()
 fns = [("8-wave (round 1)", lib.asr_diag_pwconv_presplit_8w)]
-for _sym, _label in (("asr_diag_pwconv_presplit_exp", "experiment"),):      # experiment kernels, if this diagnostic build has any
+for _sym, _label in (("asr_diag_pwconv_presplit_exp", "MOCK fused (timing only, wrong results)"),):   # csrc/gemm.hip MOCK_FUSED
     if hasattr(lib, _sym):
         fns.append((_label, getattr(lib, _sym)))
 for _n, _f in fns:
