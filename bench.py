@@ -384,6 +384,24 @@ def main():
             with open(pmc_path) as fh:
                 pmc = json.load(fh)
 
+        sq_files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_sq.json")))
+        sq = {}
+        if sq_files:       # rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES ... pass (tools/pmc_sq.sh)
+            with open(sq_files[-1]) as fh:
+                sq = json.load(fh)
+
+        def sq_lookup(prefix):
+            """Launch-time-weighted matrix-pipe occupancy of the entries whose kernel name starts with ``prefix``."""
+            hits = [(v, v["launches_sampled"] * v["avg_launch_us_profiled"]) for k, v in sq.items()
+                    if k.startswith(prefix) and v.get("mfma_pipe_busy_at_2p4ghz") is not None]
+            if not hits:
+                return None
+            tot = sum(w for _, w in hits)
+            return {"mfma_pipe_busy_at_2p4ghz": round(sum(v["mfma_pipe_busy_at_2p4ghz"] * w for v, w in hits) / tot, 4),
+                    "mfma_util_rocprof_formula": round(sum(v["mfma_util_rocprof_formula"] * w for v, w in hits) / tot, 4),
+                    "source": f"profiles/{os.path.basename(sq_files[-1])}: SQ_VALU_MFMA_BUSY_CYCLES / (1024 pipes x launch time x "
+                              "2.4 GHz) resp. / (GRBM_GUI_ACTIVE x 1024); counts K / N padding, unlike frac"}
+
         def pmc_lookup(prefix):
             """Launch-weighted mean HBM bytes of the entries whose kernel name starts with ``prefix`` (template
             arguments in the name vary by build)."""
@@ -397,6 +415,7 @@ def main():
             return {
                 "kernel": kernel, "bound": "mfma", "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(achieved / peak, 4), "peak_note": peak_note,
+                "mfma_util_pmc": sq_lookup(pmc_key),
                 "traffic": pmc_lookup(pmc_key),
                 "traffic_note": f"HBM bytes per launch from profiles/{os.path.basename(pmc_path)} (separate FETCH_SIZE / "
                                 "WRITE_SIZE passes, FETCH doubled per the gfx950 rule)",
