@@ -40,10 +40,11 @@ PRIOR_TV, PRIOR_BTV = 0, 1
 class SrConfig(C.Structure):
     """struct asr_sr_config (include/asr_hip.h): update rule + prior of the *_cfg SR entry points."""
     _fields_ = [("optimizer", C.c_int), ("flag", C.c_int), ("c0", C.c_float), ("c1", C.c_float), ("c2", C.c_float),
-                ("prior", C.c_int), ("btv_alpha", C.c_float), ("btv_shift", C.c_int)]
+                ("prior", C.c_int), ("btv_alpha", C.c_float), ("btv_shift", C.c_int), ("plane_chunk", C.c_int)]
 
 
 _cfg = C.POINTER(SrConfig)
+ABI_VERSION = 2          # ASR_ABI_VERSION of include/asr_hip.h this table mirrors
 
 # name -> (restype, argtypes).  Order and types mirror include/asr_hip.h exactly.
 SIGNATURES = {
@@ -58,6 +59,7 @@ SIGNATURES = {
     "asr_sr_backward_adam_f32": (_i, [_vp] * 10 + [_i] * 6 + [_fl] * 7 + [_i, _vp]),
     "asr_sr_loss_terms_f64": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "asr_sr_solve_workspace_bytes": (_sz, [_i] * 6),
+    "asr_sr_solve_workspace_bytes_cfg": (_sz, [_i] * 6 + [_cfg]),
     "asr_sr_solve_f32": (_i, [_vp] * 10 + [_i, _vp, _vp, _sz] + [_i] * 6 + [_fl] * 7 + [_i, _vp]),
     "asr_sr_backward_cfg_f32": (_i, [_vp] * 10 + [_i] * 6 + [_fl] * 4 + [_cfg, _vp]),
     "asr_sr_loss_terms_cfg_f64": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _cfg, _vp]),
@@ -116,8 +118,9 @@ def load():
         fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.asr_abi_version() != 1:
-        raise AsrError(f"libasr_hip.so ABI version {lib.asr_abi_version()} != 1")
+    if lib.asr_abi_version() != ABI_VERSION:
+        raise AsrError(f"libasr_hip.so ABI version {lib.asr_abi_version()} != {ABI_VERSION} (stale build? python "
+                       f"deeplabv3plus-augmented-superresolution_amd/csrc/build.py --force)")
     _lib = lib
     return lib
 

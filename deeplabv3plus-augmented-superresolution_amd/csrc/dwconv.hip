@@ -13,9 +13,9 @@
 //    bytes): register sliding window.  A thread owns (4 channels, one output column) and marches
 //    down a strip of output rows keeping the (2R+1) x 3 taps in registers; the next input rows are
 //    loaded before the current row's FMAs; no barrier, >= 4 waves per SIMD.
-//  * aspp_dw3_kernel: the three dilated ASPP depthwise convs fused -- a whole H x W x 32-channel
-//    plane (128 KB at 32x32) is staged in LDS once and all three rates are computed from it, so
-//    the input is read from HBM once instead of three times.
+//  * aspp_dw3_phase_kernel: the three dilated ASPP depthwise convs fused -- the plane is cut into its residue
+//    classes modulo gcd(rates) (on which the dilated taps close), each staged in LDS once and all three rates computed
+//    from it, so the input is read from HBM once instead of three times, on planes of any size.
 //  * dw_direct_kernel: any stride / rate, taps straight from L1/L2 (fallback).
 #include "asr_common.h"
 
@@ -265,10 +265,22 @@ __global__ __launch_bounds__(256) void dw_stream_full_kernel(DwArgs p, int tiles
 
 
 // ---------------------------------------------------------------------------------------------
-// fused ASPP: three dilation rates from one LDS-resident plane
+// fused ASPP: three dilation rates from one LDS-resident phase of the plane
 // ---------------------------------------------------------------------------------------------
-constexpr int ACB = 32;       // channels per workgroup (128-byte pieces of a pixel row)
-constexpr int ATHREADS = 512;
+// The three ASPP rates are multiples of g = gcd(rates) (6 / 12 / 18 at OS 16, 12 / 24 / 36 at OS 8): an output pixel
+// (y, x) only ever taps pixels (y + a g, x + b g), i.e. pixels of ITS OWN residue class (y mod g, x mod g).  The plane
+// therefore falls apart into g x g independent sub-grids ("phases") on which the three convs are ordinary dilated 3x3
+// convs of rates rate / g = 1, 2, 3 -- no halo, no redundancy: every input line is read from HBM exactly once and every
+// output line written once, whatever the plane size.  A workgroup owns (32 channels = one 128-byte line per pixel, one
+// row phase py, one group of gs = g / nxg adjacent column phases, one image): ceil(H / g) rows x ~W / nxg columns of
+// lines in LDS -- 24 KB on the 32 x 32 map of the 512 x 512 inputs (6 workgroups per CU: the staging loads of one overlap
+// the tap loops and the stores of the others), 46 KB on the 64 x 64 map of the 1024 x 1024 inputs (nxg = 2), where the
+// whole-plane form of round 2 (128 KB at 32 x 32, one workgroup per CU, load and compute phases strictly alternating)
+// did not fit at all and the net fell back to three dw_direct launches.
+// Taps outside the image read one zero line of LDS (the select is on the ADDRESS: one v_cndmask per tap, no branch).
+constexpr int ACB = 32;        // channels per workgroup (128-byte pieces of a pixel row)
+constexpr int ATHREADS = 256;  // 8 lanes per line, 32 lines per pass
+constexpr int AMAXCOLS = 128;  // columns of one workgroup (x-table size)
 
 struct AsppArgs {
     const float* x;
@@ -276,7 +288,8 @@ struct AsppArgs {
     const float* bias;  // [3][C]
     float* y[3];
     int batch, h, w_, c;
-    int rate[3];
+    int k[3];           // rate / g per branch
+    int g, nxg, gs;     // phase period, column-phase groups per row phase, phases per group (g = nxg * gs)
     int ldx, ldy;
     int pre_relu, post_relu;
 };
@@ -284,71 +297,83 @@ struct AsppArgs {
 // SPLIT: the three outputs in the split-f16 operand format (see dw_stream_full_kernel); a workgroup's 32 channels are
 // exactly one chunk, ldy = chunks per pixel; c % 32 == 0.
 template <bool SPLIT>
-__global__ __launch_bounds__(ATHREADS) void aspp_dw3_kernel(AsppArgs p) {
-    extern __shared__ __attribute__((aligned(16))) float plane[];  // [h*w][ACB]
+__global__ __launch_bounds__(ATHREADS) void aspp_dw3_phase_kernel(AsppArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];  // [rows * cols + 1 zero line][ACB] floats, then int xtab[cols]
     const int tid = threadIdx.x;
+    const int c4 = tid & 7, slot = tid >> 3;                     // 8 lanes x 16 bytes = one line; 32 line slots
     const int cb = blockIdx.x * ACB;
-    const int b = blockIdx.y;
-    const int hw = p.h * p.w_;
-    const float* xin = p.x + (long long)b * hw * p.ldx;
-    {   // stage the plane: 8 unconditional loads in flight per thread (clamped addresses), then the LDS stores --
-        // a load -> ReLU -> ds_write loop keeps ONE 16-byte load per thread in flight and leaves the CU idle on latency
+    const int py = blockIdx.y / p.nxg, xg = blockIdx.y - py * p.nxg;
+    const int b = blockIdx.z;
+    const int g = p.g, gs = p.gs, x0 = xg * gs;
+    const int rows = (p.h - py + g - 1) / g;                     // image rows y = py + i g
+    // columns x = q g + x0 + r (r < gs), ascending in j = q gs + r: the valid ones are the first `cols`
+    const int qfull = (p.w_ - x0) / g, rem = (p.w_ - x0) - qfull * g;
+    const int cols = (p.w_ > x0) ? qfull * gs + min(max(rem, 0), gs) : 0;
+    const int lines = rows * cols;
+    if (lines <= 0) return;
+    int* xtab = reinterpret_cast<int*>(lds + (size_t)(lines + 1) * ACB);
+    for (int j = tid; j < cols; j += ATHREADS) xtab[j] = (j / gs) * g + x0 + (j % gs);
+    if (tid < 8) *reinterpret_cast<f32x4*>(lds + (size_t)lines * ACB + tid * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* xin = p.x + (long long)b * p.h * p.w_ * p.ldx;
+    const bool ch_ok = cb + c4 * 4 < p.c;
+    {   // stage the phase: UN unconditional loads in flight per thread (clamped line index), then the LDS stores
         constexpr int UN = 8;
-        const int total = hw * (ACB / 4);
-        const int sc4 = tid & 7;                               // ATHREADS % 8 == 0: the channel quad is fixed per thread
-        const bool ch_ok = cb + sc4 * 4 < p.c;
-        const float* src = xin + (ch_ok ? cb + sc4 * 4 : 0);
+        const float* src = xin + (ch_ok ? cb + c4 * 4 : 0);
         const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-        for (int base = tid; base < total; base += ATHREADS * UN) {
+        for (int base = slot; base < lines; base += 32 * UN) {
             f32x4 v[UN];
 #pragma unroll
             for (int u = 0; u < UN; ++u) {
-                const int idx = min(base + u * ATHREADS, total - 1);
-                v[u] = *reinterpret_cast<const f32x4*>(src + (long long)(idx >> 3) * p.ldx);
+                const int l = min(base + u * 32, lines - 1);
+                const int i = l / cols, j = l - i * cols;
+                const int xx = (j / gs) * g + x0 + (j % gs);
+                v[u] = *reinterpret_cast<const f32x4*>(src + ((long long)(py + i * g) * p.w_ + xx) * p.ldx);
             }
 #pragma unroll
             for (int u = 0; u < UN; ++u) {
-                const int idx = base + u * ATHREADS;
-                if (idx < total) *reinterpret_cast<f32x4*>(plane + idx * 4) = ch_ok ? (p.pre_relu ? relu4(v[u]) : v[u]) : zero;
+                const int l = base + u * 32;
+                if (l < lines) *reinterpret_cast<f32x4*>(lds + (size_t)l * ACB + c4 * 4) = ch_ok ? (p.pre_relu ? relu4(v[u]) : v[u]) : zero;
             }
         }
     }
     __syncthreads();
-    const int c4 = tid & 7, slot = tid >> 3;  // 64 pixel slots
     const int ch = cb + c4 * 4;
     if (ch >= p.c) return;
+    const int zoff = lines * ACB + c4 * 4;
 #pragma unroll 1
     for (int br = 0; br < 3; ++br) {
-        const int rate = p.rate[br];
+        const int k = p.k[br], kj = k * gs, kx_img = k * g;
         const float* wb = p.w + (long long)br * 9 * p.c + ch;
         f32x4 wk[9];
 #pragma unroll
         for (int t = 0; t < 9; ++t) wk[t] = *reinterpret_cast<const f32x4*>(wb + (long long)t * p.c);
         const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + (long long)br * p.c + ch);
-        float* yout = p.y[br] + (long long)b * hw * p.ldy + ch;
-        for (int pix = slot; pix < hw; pix += ATHREADS / 8) {
-            const int y = pix / p.w_, x = pix - y * p.w_;
+        int i = slot / cols, j = slot - i * cols;
+        for (int l = slot; l < lines; l += 32) {
+            const int xx = xtab[j];
+            const int center = (i * cols + j) * ACB + c4 * 4;
+            const bool vyu = i - k >= 0, vyd = i + k < rows, vxl = xx - kx_img >= 0, vxr = xx + kx_img < p.w_;
+            const int up = -k * cols * ACB, dn = k * cols * ACB, lf = -kj * ACB, rt = kj * ACB;
             f32x4 acc = bv;
-#pragma unroll
-            for (int ky = 0; ky < 3; ++ky) {
-                const int iy = y + (ky - 1) * rate;
-                if (iy < 0 || iy >= p.h) continue;
-#pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    const int ix = x + (kx - 1) * rate;
-                    if (ix < 0 || ix >= p.w_) continue;
-                    acc += *reinterpret_cast<const f32x4*>(plane + ((iy * p.w_ + ix) * (ACB / 4) + c4) * 4) * wk[ky * 3 + kx];
-                }
-            }
+            acc += *reinterpret_cast<const f32x4*>(lds + ((vyu && vxl) ? center + up + lf : zoff)) * wk[0];
+            acc += *reinterpret_cast<const f32x4*>(lds + (vyu ? center + up : zoff)) * wk[1];
+            acc += *reinterpret_cast<const f32x4*>(lds + ((vyu && vxr) ? center + up + rt : zoff)) * wk[2];
+            acc += *reinterpret_cast<const f32x4*>(lds + (vxl ? center + lf : zoff)) * wk[3];
+            acc += *reinterpret_cast<const f32x4*>(lds + center) * wk[4];
+            acc += *reinterpret_cast<const f32x4*>(lds + (vxr ? center + rt : zoff)) * wk[5];
+            acc += *reinterpret_cast<const f32x4*>(lds + ((vyd && vxl) ? center + dn + lf : zoff)) * wk[6];
+            acc += *reinterpret_cast<const f32x4*>(lds + (vyd ? center + dn : zoff)) * wk[7];
+            acc += *reinterpret_cast<const f32x4*>(lds + ((vyd && vxr) ? center + dn + rt : zoff)) * wk[8];
             acc = post_act4(acc, p.post_relu);
+            const long long pix = (long long)b * p.h * p.w_ + (long long)(py + i * g) * p.w_ + xx;
             if (SPLIT) {
                 f16x4 hi, lo;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    _Float16 h, l;
-                    asr_split_f16(acc[e], h, l);
+                    _Float16 h, l2;
+                    asr_split_f16(acc[e], h, l2);
                     hi[e] = h;
-                    lo[e] = l;
+                    lo[e] = l2;
                 }
                 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
                 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -359,12 +384,13 @@ __global__ __launch_bounds__(ATHREADS) void aspp_dw3_kernel(AsppArgs p) {
                 got.x = (unsigned int)__builtin_amdgcn_mov_dpp((int)give.x, 0xB1, 0xF, 0xF, true);
                 got.y = (unsigned int)__builtin_amdgcn_mov_dpp((int)give.y, 0xB1, 0xF, 0xF, true);
                 const u32x4 out = even ? u32x4{h2.x, h2.y, got.x, got.y} : u32x4{got.x, got.y, l2.x, l2.y};
-                _Float16* o = reinterpret_cast<_Float16*>(p.y[br]) + (((long long)b * hw + pix) * p.ldy + (cb >> 5)) * 64 +
-                              (even ? c4 * 4 : 32 + (c4 - 1) * 4);
-                *reinterpret_cast<u32x4*>(o) = out;
+                _Float16* o = reinterpret_cast<_Float16*>(p.y[br]) + (pix * p.ldy + (cb >> 5)) * 64 + (even ? c4 * 4 : 32 + (c4 - 1) * 4);
+                if (kNtStores) __builtin_nontemporal_store(out, reinterpret_cast<u32x4*>(o)); else *reinterpret_cast<u32x4*>(o) = out;
             } else {
-                *reinterpret_cast<f32x4*>(yout + (long long)pix * p.ldy) = acc;
+                *reinterpret_cast<f32x4*>(p.y[br] + pix * p.ldy + ch) = acc;
             }
+            j += 32;
+            while (j >= cols) { j -= cols; ++i; }
         }
     }
 }
@@ -501,6 +527,28 @@ extern "C" int asr_dwconv3x3_nhwc_split_f16(const float* x, const float* w, cons
     return ASR_OK;
 }
 
+static int asr_gcd(int a, int b) { while (b) { const int t = a % b; a = b; b = t; } return a; }
+
+// Geometry of the phase decomposition: g = gcd of the rates; the column phases are split into nxg groups (a divisor of g)
+// until a workgroup's lines fit 48 KB of LDS (>= 3 workgroups per CU), or as far as g allows.
+static int aspp_geometry(int h, int w, int rate0, int rate1, int rate2, int* g_out, int* nxg_out, size_t* lds_out) {
+    const int g = asr_gcd(asr_gcd(rate0, rate1), rate2);
+    const int rows = (h + g - 1) / g;
+    int nxg = 1;
+    size_t lds = 0;
+    for (;;) {
+        const int gs = g / nxg;
+        const int cols = ((w + g - 1) / g) * gs;                     // upper bound over the column-phase groups
+        lds = sizeof(float) * ((size_t)rows * cols + 1) * ACB + sizeof(int) * (size_t)cols;
+        if ((lds <= 48 * 1024 && cols <= AMAXCOLS) || nxg == g) break;
+        int next = nxg + 1;
+        while (g % next) ++next;
+        nxg = next;
+    }
+    *g_out = g; *nxg_out = nxg; *lds_out = lds;
+    return ((w + g - 1) / g) * (g / nxg) <= AMAXCOLS && lds <= 160 * 1024;
+}
+
 static int aspp_common(bool split, const float* x, const float* w3, const float* bias3, void* y0, void* y1, void* y2, int batch,
                        int h, int w, int c, int rate0, int rate1, int rate2, int ldx, int ldy, int pre_relu, int post_relu,
                        asr_stream_t stream) {
@@ -514,20 +562,26 @@ static int aspp_common(bool split, const float* x, const float* w3, const float*
                     "asr_aspp_dwconv3: x, w3, bias3 must be 16-byte aligned");
     ASR_UNSUPPORTED((reinterpret_cast<uintptr_t>(y0) | reinterpret_cast<uintptr_t>(y1) | reinterpret_cast<uintptr_t>(y2)) & (split ? 127 : 15),
                     "asr_aspp_dwconv3: outputs must be 16-byte (split: 128-byte) aligned");
-    const size_t lds = sizeof(float) * (size_t)h * w * ACB;
-    ASR_UNSUPPORTED(lds > 160 * 1024, "asr_aspp_dwconv3: %dx%d plane x %d channels (%zu B) exceeds the 160 KB LDS; "
-                    "use asr_dwconv3x3_nhwc_f32 per branch", h, w, ACB, lds);
+    int g = 1, nxg = 1;
+    size_t lds = 0;
+    const int fits = aspp_geometry(h, w, rate0, rate1, rate2, &g, &nxg, &lds);
+    ASR_UNSUPPORTED(!fits, "asr_aspp_dwconv3: a phase of the %dx%d plane at rates %d/%d/%d (period %d) needs %zu B of LDS (max 160 KB); "
+                    "use asr_dwconv3x3_nhwc_f32 per branch", h, w, rate0, rate1, rate2, g, lds);
+    ASR_UNSUPPORTED((long long)g * nxg > 65535, "asr_aspp_dwconv3: too many phases (%d x %d)", g, nxg);
     static AsrDeviceOnce once_f32, once_split;
-    ASR_HIP_CHECK(asr_allow_dynamic_lds(once_f32, reinterpret_cast<const void*>(aspp_dw3_kernel<false>), 160 * 1024));
-    ASR_HIP_CHECK(asr_allow_dynamic_lds(once_split, reinterpret_cast<const void*>(aspp_dw3_kernel<true>), 160 * 1024));
+    if (lds > 64 * 1024) {
+        ASR_HIP_CHECK(asr_allow_dynamic_lds(once_f32, reinterpret_cast<const void*>(aspp_dw3_phase_kernel<false>), 160 * 1024));
+        ASR_HIP_CHECK(asr_allow_dynamic_lds(once_split, reinterpret_cast<const void*>(aspp_dw3_phase_kernel<true>), 160 * 1024));
+    }
     AsppArgs p{};
     p.x = x; p.w = w3; p.bias = bias3;
     p.y[0] = static_cast<float*>(y0); p.y[1] = static_cast<float*>(y1); p.y[2] = static_cast<float*>(y2);
-    p.batch = batch; p.h = h; p.w_ = w; p.c = c; p.rate[0] = rate0; p.rate[1] = rate1; p.rate[2] = rate2;
+    p.batch = batch; p.h = h; p.w_ = w; p.c = c; p.k[0] = rate0 / g; p.k[1] = rate1 / g; p.k[2] = rate2 / g;
+    p.g = g; p.nxg = nxg; p.gs = g / nxg;
     p.ldx = ldx; p.ldy = ldy; p.pre_relu = pre_relu; p.post_relu = post_relu;
-    const dim3 grid((unsigned)asr_cdiv(c, ACB), batch);
-    if (split) hipLaunchKernelGGL(aspp_dw3_kernel<true>, grid, dim3(ATHREADS), lds, asr_stream(stream), p);
-    else hipLaunchKernelGGL(aspp_dw3_kernel<false>, grid, dim3(ATHREADS), lds, asr_stream(stream), p);
+    const dim3 grid((unsigned)asr_cdiv(c, ACB), (unsigned)(g * nxg), batch);
+    if (split) hipLaunchKernelGGL(aspp_dw3_phase_kernel<true>, grid, dim3(ATHREADS), lds, asr_stream(stream), p);
+    else hipLaunchKernelGGL(aspp_dw3_phase_kernel<false>, grid, dim3(ATHREADS), lds, asr_stream(stream), p);
     ASR_LAUNCH_CHECK();
     return ASR_OK;
 }

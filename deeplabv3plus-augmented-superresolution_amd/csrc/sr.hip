@@ -344,8 +344,11 @@ constexpr int kGrRows = 16;   // HR rows per wave of sr_grad_translate_kernel
 template <int LOG2F>
 __global__ __launch_bounds__(256) void sr_grad_translate_kernel(const float* __restrict__ resid,
                                                                 const float* __restrict__ inv_trans_tf,
-                                                                float* __restrict__ gr_out, SrDims d, float two_lambda_df) {
-    const int bn = blockIdx.z;
+                                                                float* __restrict__ gr_out, SrDims d, float two_lambda_df,
+                                                                int n0, int cn) {
+    // blockIdx.z = b * cn + local: copy n0 + local of image b, written to plane slot blockIdx.z of the chunk's planes
+    const int slot = blockIdx.z;
+    const int bn = (slot / cn) * d.n + n0 + (slot % cn);
     const int lane = threadIdx.x;
     const int cx = blockIdx.x * 64 + lane;
     const int cy0 = (blockIdx.y * 4 + __builtin_amdgcn_readfirstlane(threadIdx.y)) * kGrRows;
@@ -354,7 +357,7 @@ __global__ __launch_bounds__(256) void sr_grad_translate_kernel(const float* __r
     const int WP = W + 2 * kGrPadX;
     const float* r = resid + (int64_t)bn * lh * lw;
     const AsrTf8 it = asr_load_tf(inv_trans_tf + (int64_t)bn * 8);
-    float* const out = gr_out + (size_t)bn * sr_gr_plane_elems(H, W) + (size_t)kGrPadY * WP + kGrPadX;
+    float* const out = gr_out + (size_t)slot * sr_gr_plane_elems(H, W) + (size_t)kGrPadY * WP + kGrPadX;
     const bool col_ok = cx < W;
     const bool pure_translation = (it.a0 == 1.0f && it.a1 == 0.0f && it.b0 == 0.0f && it.b1 == 1.0f &&
                                    it.c0 == 0.0f && it.c1 == 0.0f);
@@ -559,25 +562,31 @@ __device__ __forceinline__ float sr_gather_chunk(float g_df, const float* __rest
     return g_df;
 }
 
+// The copies are taken in chunks [n0, n0 + cn) (one launch per chunk, the chunk's planes written by the K_gt launch before
+// it): the running sum of the data-term gradient crosses the launches through `acc` [batch, H, W] as a float32 -- the same
+// sequence of float32 additions, in copy order, as one pass over all copies, so the result does not depend on the chunking.
+// The last chunk adds the priors and applies the update.
 __global__ __launch_bounds__(256) void sr_backward_gather_kernel(
     const float* __restrict__ x, float* __restrict__ x_new, const float* __restrict__ gr_planes,
     const float* __restrict__ inv_rot_tf, float* __restrict__ m, float* __restrict__ v, float* __restrict__ vhat,
     const float* __restrict__ alphas, float* __restrict__ grad_out, SrDims d, float lambda_tv, float two_lambda_l2,
-    float lambda_l1, SrStep st, float* __restrict__ x_bordered_out) {
+    float lambda_l1, SrStep st, float* __restrict__ x_bordered_out, float* __restrict__ acc, int n0, int cn) {
     const int X = blockIdx.x * 64 + threadIdx.x;
     const int Y = blockIdx.y * 4 + threadIdx.y;
     const int b = blockIdx.z;
     const int H = d.H, W = d.W, WP = W + 2 * kGrPadX;
     if (X >= W || Y >= H) return;
     const size_t plane = sr_gr_plane_elems(H, W);
-    const float* const planes = gr_planes + (size_t)b * d.n * plane;
-    const float* const tfs = inv_rot_tf + (int64_t)b * d.n * 8;
+    const float* const planes = gr_planes + (size_t)b * cn * plane;
+    const float* const tfs = inv_rot_tf + ((int64_t)b * d.n + n0) * 8;
     const float fx = (float)X, fy = (float)Y;
-    float g_df = 0.0f;
+    const int64_t o = ((int64_t)b * H + Y) * W + X;
+    float g_df = (n0 == 0) ? 0.0f : acc[o];
     int n = 0;
-    for (; n + 8 <= d.n; n += 8) g_df = sr_gather_chunk<8>(g_df, tfs + n * 8, planes + n * plane, plane, WP, H, W, fx, fy);
-    if (n + 4 <= d.n) { g_df = sr_gather_chunk<4>(g_df, tfs + n * 8, planes + n * plane, plane, WP, H, W, fx, fy); n += 4; }
-    for (; n < d.n; ++n) g_df = sr_gather_chunk<1>(g_df, tfs + n * 8, planes + n * plane, plane, WP, H, W, fx, fy);
+    for (; n + 8 <= cn; n += 8) g_df = sr_gather_chunk<8>(g_df, tfs + n * 8, planes + n * plane, plane, WP, H, W, fx, fy);
+    if (n + 4 <= cn) { g_df = sr_gather_chunk<4>(g_df, tfs + n * 8, planes + n * plane, plane, WP, H, W, fx, fy); n += 4; }
+    for (; n < cn; ++n) g_df = sr_gather_chunk<1>(g_df, tfs + n * 8, planes + n * plane, plane, WP, H, W, fx, fy);
+    if (n0 + cn < d.n) { acc[o] = g_df; return; }
     sr_prior_and_update(x, x_new, m, v, vhat, alphas, grad_out, d, b, X, Y, g_df, lambda_tv, two_lambda_l2, lambda_l1, st,
                         x_bordered_out);
 }
@@ -594,7 +603,7 @@ SrBwdKernel sr_backward_kernel_for(int f) {
     }
 }
 
-typedef void (*SrGradTranslateKernel)(const float*, const float*, float*, SrDims, float);
+typedef void (*SrGradTranslateKernel)(const float*, const float*, float*, SrDims, float, int, int);
 SrGradTranslateKernel sr_grad_translate_kernel_for(int f) {
     switch (f) {
         case 2: return sr_grad_translate_kernel<1>;
@@ -758,8 +767,24 @@ int prepare_backward(const SrDims& d) {
         ASR_HIP_CHECK(asr_allow_dynamic_lds(once[idx], reinterpret_cast<const void*>(sr_backward_kernel_for(d.f)), 160 * 1024));
     return ASR_OK;
 }
-dim3 gr_grid(const SrDims& d) {
-    return dim3((unsigned)asr_cdiv(d.W, 64), (unsigned)asr_cdiv(d.H, 4 * kGrRows), (unsigned)(d.batch * d.n));
+dim3 gr_grid(const SrDims& d, int cn) {
+    return dim3((unsigned)asr_cdiv(d.W, 64), (unsigned)asr_cdiv(d.H, 4 * kGrRows), (unsigned)(d.batch * cn));
+}
+// Copies whose gradient planes are alive at once.  The planes (1.07 MB each at 512 x 512) are written by K_gt and read
+// back by K_bwd in the same iteration; all N at once is 107 MB at N = 100 and 214 MB per image at N = 200 (two images in
+// flight: past the 256 MB Infinity Cache).  <= 32 copies keep <= 35 MB live per image.  Even split of n into the fewest
+// such chunks; cfg->plane_chunk overrides (>= n: everything in one chunk, the round-2 form).
+constexpr int kPlaneChunkMax = 32;
+int sr_plane_chunk(int n, int requested) {
+    if (requested > 0) return requested < n ? requested : n;
+    const int chunks = (n + kPlaneChunkMax - 1) / kPlaneChunkMax;
+    return (n + chunks - 1) / chunks;
+}
+size_t sr_workspace_bytes(int batch, int n, int H, int W, int h, int w, int chunk) {
+    // residuals [batch*n, h, w] + the ping-pong x [batch, H, W] + the running data-term sum [batch, H, W] + the
+    // zero-bordered planes [H + 4, W + 8]: G_R per copy of a chunk, x per image
+    return sizeof(float) * ((size_t)batch * n * h * w + 2 * (size_t)batch * H * W +
+                            ((size_t)batch * chunk + batch) * sr_gr_plane_elems(H, W));
 }
 dim3 gather_grid(const SrDims& d) {
     return dim3((unsigned)asr_cdiv(d.W, 64), (unsigned)asr_cdiv(d.H, 4), (unsigned)d.batch);
@@ -831,6 +856,7 @@ asr_sr_config adam_tv_config(float one_minus_beta1, float one_minus_beta2, float
     asr_sr_config c{};
     c.optimizer = ASR_OPT_ADAM; c.flag = amsgrad; c.c0 = one_minus_beta1; c.c1 = one_minus_beta2; c.c2 = epsilon;
     c.prior = ASR_PRIOR_TV;
+    c.plane_chunk = 0;
     return c;
 }
 
@@ -895,8 +921,11 @@ extern "C" int asr_sr_loss_terms_f64(const float* x, const float* resid, double*
 }
 
 extern "C" size_t asr_sr_solve_workspace_bytes(int batch, int n, int H, int W, int h, int w) {
-    // residuals [batch*n, h, w] + the ping-pong x [batch, H, W] + the zero-bordered planes [H + 4, W + 8]: G_R per copy, x per image
-    return sizeof(float) * ((size_t)batch * n * h * w + (size_t)batch * H * W + ((size_t)batch * n + batch) * sr_gr_plane_elems(H, W));
+    return sr_workspace_bytes(batch, n, H, W, h, w, sr_plane_chunk(n, 0));
+}
+
+extern "C" size_t asr_sr_solve_workspace_bytes_cfg(int batch, int n, int H, int W, int h, int w, const asr_sr_config* cfg) {
+    return sr_workspace_bytes(batch, n, H, W, h, w, sr_plane_chunk(n, cfg ? cfg->plane_chunk : 0));
 }
 
 // The whole optimisation loop of augmented_superresolution (superresolution.py:120-135) as one
@@ -919,7 +948,10 @@ extern "C" int asr_sr_solve_cfg_f32(float* x, const float* y, const float* rot_t
     SrStep st;
     rc = make_step("asr_sr_solve_cfg_f32", cfg, true, m, v, vhat, &st);
     if (rc != ASR_OK) return rc;
-    const size_t need = asr_sr_solve_workspace_bytes(batch, n, H, W, h, w);
+    ASR_REQUIRE(cfg->plane_chunk >= 0, "asr_sr_solve_cfg_f32: plane_chunk %d < 0", cfg->plane_chunk);
+    const int chunk = sr_plane_chunk(n, cfg->plane_chunk);
+    ASR_REQUIRE((int64_t)batch * chunk <= 65535, "asr_sr_solve_cfg_f32: batch*chunk=%lld exceeds 65535 (grid.z)", (long long)batch * chunk);
+    const size_t need = sr_workspace_bytes(batch, n, H, W, h, w, chunk);
     if (workspace_bytes < need) {
         asr_set_error("asr_sr_solve_cfg_f32: workspace %zu < required %zu bytes", workspace_bytes, need);
         return ASR_ERR_WORKSPACE;
@@ -929,12 +961,13 @@ extern "C" int asr_sr_solve_cfg_f32(float* x, const float* y, const float* rot_t
     float* x_alt = resid + (size_t)batch * n * h * w;
     float* cur = x;
     float* nxt = x_alt;
-    float* const gr = x_alt + (size_t)batch * H * W;
+    float* const acc = x_alt + (size_t)batch * H * W;   // running data-term sum between the chunks of an iteration
+    float* const gr = acc + (size_t)batch * H * W;
     const SrGradTranslateKernel gr_kernel = sr_grad_translate_kernel_for(d.f);
-    float* const xb = gr + (size_t)batch * n * sr_gr_plane_elems(H, W);   // bordered copy of the current x
+    float* const xb = gr + (size_t)batch * chunk * sr_gr_plane_elems(H, W);   // bordered copy of the current x
     if (num_iter > 0) {   // the borders stay zero for the whole solve; the interiors are rewritten every iteration
         const size_t pe = sr_gr_plane_elems(H, W);
-        ASR_HIP_CHECK(hipMemsetAsync(gr, 0, sizeof(float) * ((size_t)batch * n + batch) * pe, s));
+        ASR_HIP_CHECK(hipMemsetAsync(gr, 0, sizeof(float) * ((size_t)batch * chunk + batch) * pe, s));
         const size_t wp = (size_t)W + 2 * kGrPadX;
         for (int b = 0; b < batch; ++b)
             ASR_HIP_CHECK(hipMemcpy2DAsync(xb + b * pe + kGrPadY * wp + kGrPadX, wp * sizeof(float), x + (size_t)b * H * W,
@@ -948,11 +981,15 @@ extern "C" int asr_sr_solve_cfg_f32(float* x, const float* y, const float* rot_t
             rc = asr_sr_loss_terms_cfg_f64(cur, resid, last_loss_terms, batch, n, H, W, h, w, cfg, stream);
             if (rc != ASR_OK) return rc;
         }
-        hipLaunchKernelGGL(gr_kernel, gr_grid(d), dim3(64, 4), 0, s, resid, inv_trans_tf, gr, d, 2.0f * lambda_df);
-        ASR_LAUNCH_CHECK();
-        hipLaunchKernelGGL(sr_backward_gather_kernel, gather_grid(d), dim3(64, 4), 0, s, cur, nxt, gr, inv_rot_tf, m, v, vhat,
-                           alphas + (size_t)it * batch, (float*)nullptr, d, lambda_tv, 2.0f * lambda_l2, lambda_l1, st, xb);
-        ASR_LAUNCH_CHECK();
+        for (int n0 = 0; n0 < n; n0 += chunk) {
+            const int cn = n - n0 < chunk ? n - n0 : chunk;
+            hipLaunchKernelGGL(gr_kernel, gr_grid(d, cn), dim3(64, 4), 0, s, resid, inv_trans_tf, gr, d, 2.0f * lambda_df, n0, cn);
+            ASR_LAUNCH_CHECK();
+            hipLaunchKernelGGL(sr_backward_gather_kernel, gather_grid(d), dim3(64, 4), 0, s, cur, nxt, gr, inv_rot_tf, m, v, vhat,
+                               alphas + (size_t)it * batch, (float*)nullptr, d, lambda_tv, 2.0f * lambda_l2, lambda_l1, st, xb,
+                               acc, n0, cn);
+            ASR_LAUNCH_CHECK();
+        }
         float* t = cur; cur = nxt; nxt = t;
     }
     if (cur != x) ASR_HIP_CHECK(hipMemcpyAsync(x, cur, sizeof(float) * (size_t)batch * H * W, hipMemcpyDeviceToDevice, s));

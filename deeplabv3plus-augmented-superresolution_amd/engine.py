@@ -449,9 +449,11 @@ class DeeplabEngine:
         release(pp)
         pw(x, "aspp0", out=cat, out_off=256, relu=True)
         rates = self.atrous_rates
-        if fh * fw * 128 <= 160 * 1024 and "fused_aspp" not in self.disabled:
-            # the three dilated depthwise convs read the same input: one fused launch stages each
-            # 32-channel plane in LDS once (input read from HBM 1x instead of 3x)
+        g = int(np.gcd.reduce(rates))
+        if (-(-fh // g) * -(-fw // g) + 1) * 128 + 256 <= 160 * 1024 and "fused_aspp" not in self.disabled:
+            # the three dilated depthwise convs read the same input: one fused launch stages each residue class of the
+            # plane (modulo gcd(rates), on which the taps close) in LDS once -- input read from HBM 1x instead of 3x, on
+            # planes of any size (csrc/dwconv.hip: aspp_dw3_phase_kernel)
             ts = [new((b, fh, fw, fc)) for _ in rates]
             p3 = self.p["aspp_dw3"]
             split = (all(self.p[f"aspp{i + 1}_pointwise"].get("fn", "").endswith("f16x3") for i in range(3)) and fc % 32 == 0
@@ -459,7 +461,7 @@ class DeeplabEngine:
             add("asr_aspp_dwconv3_nhwc_split_f16" if split else "asr_aspp_dwconv3_nhwc_f32",
                 (x.ptr, p3["w"].data_ptr(), p3["b"].data_ptr(), ts[0].ptr, ts[1].ptr, ts[2].ptr, b, fh, fw, fc,
                  rates[0], rates[1], rates[2], x.ld, fc // 32 if split else ts[0].ld, 0, 1),
-                "dw", 3 * 18.0 * b * fh * fw * fc, 3 * 4.0 * 2 * b * fh * fw * fc,
+                "dw", 3 * 18.0 * b * fh * fw * fc, 4.0 * (1 + 3) * b * fh * fw * fc,       # bytes MOVED: input once, three outputs
                 label=f"aspp_dw3 {fh}x{fw}x{fc} r{rates[0]}/{rates[1]}/{rates[2]} fused" + (" split" if split else ""), out=ts)
             for i, t in enumerate(ts):
                 if split:

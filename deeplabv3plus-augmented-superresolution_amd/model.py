@@ -126,6 +126,7 @@ class DeeplabModel:
         for i in range(0, n, batch_size):
             xb = x[i:i + batch_size].to(self.device, non_blocking=True).contiguous()
             logits = self.engine.forward(xb, profile=profile, lane=lane)
+            self._raw_logits = logits       # pre-activation, pre-upsample logits of the LAST batch (plan memory)
             if self.final_upsample:
                 logits = self._upsample(logits, (h, w))
             elif clone or n > batch_size:
@@ -140,6 +141,15 @@ class DeeplabModel:
         if self.last_activation in ("softmax", "sigmoid"):
             out = ops.class_activation(out.contiguous(), self.last_activation)
         return out
+
+    def logits_of(self, preds, i):
+        """Row i of the raw logits behind ``preds`` = the return value of the LAST single-batch predict_device call: preds[i]
+        itself without a last_activation, else the plan's logits buffer (valid until the next forward of that shape and lane).
+        The standard-output mask is taken from logits whatever the hot path's activation (generate_standard_output.py:82-86
+        builds its model with last_activation=None)."""
+        if self.last_activation in ("softmax", "sigmoid") and not self.final_upsample:
+            return self._raw_logits[i]
+        return preds[i]
 
     def calibrate_range(self, x):
         """Range guard of the split-f16 GEMMs on a probe batch x [B,H,W,3] (host array or device tensor): layers whose

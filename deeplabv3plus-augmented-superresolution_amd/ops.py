@@ -110,10 +110,12 @@ def sr_forward_residual(x, y, rot_tf, trans_tf):
     return resid
 
 
-def sr_config(optimizer=_lib.OPT_ADAM, flag=False, c0=0.0, c1=0.0, c2=0.0, use_btv=False, btv_alpha=0.6, btv_shift=2):
-    """asr_sr_config for the *_cfg entry points (meaning of c0..c2 per optimizer: include/asr_hip.h)."""
+def sr_config(optimizer=_lib.OPT_ADAM, flag=False, c0=0.0, c1=0.0, c2=0.0, use_btv=False, btv_alpha=0.6, btv_shift=2,
+              plane_chunk=0):
+    """asr_sr_config for the *_cfg entry points (meaning of c0..c2 per optimizer: include/asr_hip.h).  plane_chunk: copies
+    whose gradient planes the solver keeps alive at once (0 = library default, <= 32; results do not depend on it)."""
     return _lib.SrConfig(int(optimizer), int(bool(flag)), float(c0), float(c1), float(c2),
-                         _lib.PRIOR_BTV if use_btv else _lib.PRIOR_TV, float(btv_alpha), int(btv_shift))
+                         _lib.PRIOR_BTV if use_btv else _lib.PRIOR_TV, float(btv_alpha), int(btv_shift), int(plane_chunk))
 
 
 def _adam_config(one_minus_beta1, one_minus_beta2, epsilon, amsgrad):
@@ -180,10 +182,11 @@ def sr_loss_terms(x, resid, cfg=None):
 
 
 def sr_solve(x, y, rot_tf, trans_tf, inv_rot_tf, inv_trans_tf, alphas, lambdas, one_minus_beta1=None, one_minus_beta2=None,
-             epsilon=None, amsgrad=False, want_loss=True, cfg=None, slot_init=None):
+             epsilon=None, amsgrad=False, want_loss=True, cfg=None, slot_init=None, state=None):
     """Runs alphas.shape[0] iterations in place on x.  alphas [num_iter, B] (device).  Either the Adam
     hyper-parameters (asr_sr_solve_f32) or cfg (+ slot_init = {"m"/"v"/"vhat": initial value}) for
-    asr_sr_solve_cfg_f32."""
+    asr_sr_solve_cfg_f32.  state: a dict that carries the optimiser slots and the workspace from one call to the next --
+    a solve cut into several calls (the verbose loss print-outs) then performs exactly the updates of a single call."""
     b, n, H, W, h, w = _sr_dims(x, y)
     for t, name in ((rot_tf, "rot_tf"), (trans_tf, "trans_tf"), (inv_rot_tf, "inv_rot_tf"), (inv_trans_tf, "inv_trans_tf")):
         _check_tf(t, b, n, name)
@@ -191,12 +194,18 @@ def sr_solve(x, y, rot_tf, trans_tf, inv_rot_tf, inv_trans_tf, alphas, lambdas, 
         raise AsrError(f"alphas must be [num_iter,{b}]")
     num_iter = alphas.shape[0]
     lib = _lib.load()
-    ws_bytes = lib.asr_sr_solve_workspace_bytes(b, n, H, W, h, w)
-    ws = torch.empty((ws_bytes + 3) // 4, dtype=f32, device=x.device)
-    init = slot_init or {}
-    m = torch.full_like(x, float(init.get("m", 0.0)))
-    v = torch.full_like(x, float(init.get("v", 0.0)))
-    vhat = torch.full_like(x, float(init.get("vhat", 0.0)))
+    ws_bytes = (lib.asr_sr_solve_workspace_bytes(b, n, H, W, h, w) if cfg is None else
+                lib.asr_sr_solve_workspace_bytes_cfg(b, n, H, W, h, w, C.byref(cfg)))
+    if state is not None and "ws" in state:
+        ws, m, v, vhat = state["ws"], state["m"], state["v"], state["vhat"]
+    else:
+        ws = torch.empty((ws_bytes + 3) // 4, dtype=f32, device=x.device)
+        init = slot_init or {}
+        m = torch.full_like(x, float(init.get("m", 0.0)))
+        v = torch.full_like(x, float(init.get("v", 0.0)))
+        vhat = torch.full_like(x, float(init.get("vhat", 0.0)))
+        if state is not None:
+            state.update(ws=ws, m=m, v=v, vhat=vhat)
     terms = torch.zeros((b, 4), dtype=torch.float64, device=x.device) if want_loss else None
     if cfg is None:
         call("asr_sr_solve_f32", ptr(x), ptr(y), ptr(rot_tf), ptr(trans_tf), ptr(inv_rot_tf), ptr(inv_trans_tf), ptr(m),
@@ -292,29 +301,38 @@ def argmax(logits):
     return out
 
 
-def opm_argmax(logits, class_id):
+def _opm_out(out, logits, name):
+    """out: optional contiguous [N,h,w] float32 destination (a slice of a per-image stack), else a new tensor."""
+    if out is None:
+        return torch.empty(logits.shape[:-1], dtype=f32, device=logits.device)
+    if tuple(out.shape) != tuple(logits.shape[:-1]) or not out.is_contiguous():
+        raise AsrError(f"{name}: out must be a contiguous {tuple(logits.shape[:-1])} tensor, got {tuple(out.shape)}")
+    return out
+
+
+def opm_argmax(logits, class_id, out=None):
     classes = logits.shape[-1]
     pixels = logits.numel() // classes
-    out = torch.empty(logits.shape[:-1], dtype=f32, device=logits.device)
+    out = _opm_out(out, logits, "opm_argmax")
     call("asr_opm_argmax_f32", ptr(logits), ptr(out), pixels, classes, class_id, stream_ptr())
     return out
 
 
-def opm_slice_max(logits, class_id):
+def opm_slice_max(logits, class_id, out=None, out_max=None):
     classes = logits.shape[-1]
     pixels = logits.numel() // classes
-    cls = torch.empty(logits.shape[:-1], dtype=f32, device=logits.device)
-    mx = torch.empty_like(cls)
+    cls = _opm_out(out, logits, "opm_slice_max")
+    mx = _opm_out(out_max, logits, "opm_slice_max")
     call("asr_opm_slice_max_f32", ptr(logits), ptr(cls), ptr(mx), pixels, classes, class_id, stream_ptr())
     return cls, mx
 
 
-def opm_slice(logits, class_id, new_min=0.0, new_max=1.0):
+def opm_slice(logits, class_id, new_min=0.0, new_max=1.0, out=None):
     """logits [N,h,w,C]: per-copy global min/max normalisation of the class slice."""
     n = logits.shape[0]
     classes = logits.shape[-1]
     per_copy = logits.numel() // (n * classes)
-    out = torch.empty(logits.shape[:-1], dtype=f32, device=logits.device)
+    out = _opm_out(out, logits, "opm_slice")
     ws = torch.empty((n, 2), dtype=f32, device=logits.device)
     call("asr_opm_slice_f32", ptr(logits), ptr(out), ptr(ws), n, per_copy, classes, class_id, float(new_min),
          float(new_max), stream_ptr())

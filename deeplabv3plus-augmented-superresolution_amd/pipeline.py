@@ -42,29 +42,44 @@ class HotPath:
 
     # ---- stage 1 (model stream): augment -> forward -> OPM (-> standard mask) --------------------------
     def _stage_model(self, image_dev, angles, shifts, profile=None, want_standard=True, lane=0):
+        """The copies go through the model one forward batch at a time (augmentation_utils.py:30-59 draws them in chunks
+        for the same reason): each batch is augmented straight into the plan's input buffer, its logits are consumed in
+        place by the OPM kernel, which writes its rows of the image's [N,h,w] stack -- nothing of size [N,H,W,3] or
+        [N,h,w,classes] outlives a batch."""
         out_hw = self.sr.output_size
         n = len(angles)
         h, w, _ = image_dev.shape
-        if n <= self.batch_size:      # one forward pass: the copies are written straight into the plan's input buffer, the
-            copies = au.augment_on_device(image_dev, angles, shifts, out=self.model.engine.input_view(n, h, w, lane))
-            preds = self.model.predict_device(copies, batch_size=n, profile=profile, lane=lane, clone=False)   # logits stay there
-        else:
-            copies = au.augment_on_device(image_dev, angles, shifts)
-            preds = self.model.predict_device(copies, batch_size=self.batch_size, profile=profile, lane=lane)
-        del copies
-        cls, mx = au.output_processing(preds, self.class_id, self.mode)
-        # the image's masks live in one [4, H, W] int32 buffer (rows MASK_KEYS): the IoU kernel reads it as it stands
-        res = {"_masks": torch.empty((len(self.MASK_KEYS),) + tuple(out_hw), dtype=torch.int32, device=preds.device)}
-        if want_standard:
-            res["standard"] = self.standard_mask(preds[0], out_hw, out=res["_masks"][0])
-        del preds
-        y = cls[None]
-        ymax = mx[None] if mx is not None else None
+        eng = self.model.engine
+        bs = min(self.batch_size, n)
+        fh, fw = h // eng.output_stride, w // eng.output_stride
+        y = torch.empty((1, n, fh, fw), dtype=torch.float32, device=image_dev.device)
+        ymax = torch.empty_like(y) if self.mode == "slice_max" else None
+        res = {"_masks": torch.empty((len(self.MASK_KEYS),) + tuple(out_hw), dtype=torch.int32, device=image_dev.device)}
+        for i in range(0, n, bs):
+            k = min(bs, n - i)
+            copies = au.augment_on_device(image_dev, angles[i:i + k], shifts[i:i + k], out=eng.input_view(k, h, w, lane))
+            preds = self.model.predict_device(copies, batch_size=k, profile=profile, lane=lane, clone=False)  # logits stay there
+            if i == 0 and want_standard:
+                res["standard"] = self.standard_mask(self.model.logits_of(preds, 0), out_hw, out=res["_masks"][0])
+            au.output_processing(preds, self.class_id, self.mode, out=y[0, i:i + k],
+                                 out_max=ymax[0, i:i + k] if ymax is not None else None)
+            del copies, preds
         if self.mode != "slice":            # load_SR_data's global min-max normalisation (superres_utils.py:183-192)
             y = self._normalise(y)
             if ymax is not None:
                 ymax = self._normalise(ymax)
         return res, y, ymax
+
+    def _sr_frame(self, image_dev, shifts):
+        """The SR stage applies the copies' shifts in ITS pixel frame (superresolution.py:61-64 translates the HR estimate,
+        of output_size).  The reference always runs with image size == output_size; when they differ (BASELINE configs[4]:
+        1024 x 1024 inputs, 512 x 512 SR output) a shift of s input pixels is s * output_size / image_size output pixels
+        (per axis; shifts are [dx, dy]).  Angles are frame-independent."""
+        h, w, _ = image_dev.shape
+        H, Wd = self.sr.output_size
+        if (h, w) == (H, Wd):
+            return shifts
+        return (np.asarray(shifts, dtype=np.float32) * np.array([Wd / w, H / h], dtype=np.float32)).astype(np.float32)
 
     # ---- stage 2 (any stream): ASR solve, max / mean realign, threshold, IoU counts --------------------
     def _stage_sr(self, res, y, ymax, angles, shifts, gt_dev, adam_start, sr_types):
@@ -96,7 +111,7 @@ class HotPath:
         """image_dev [H,W,3] float32 device; angles [N], shifts [N,2] float32 host arrays;
         gt_dev [H,W] int32 device labels (optional).  Returns dict of device masks (+ 6 IoUs)."""
         res, y, ymax = self._stage_model(image_dev, angles, shifts, profile, want_standard)
-        res = self._stage_sr(res, y, ymax, angles, shifts, gt_dev, adam_start, sr_types)
+        res = self._stage_sr(res, y, ymax, angles, self._sr_frame(image_dev, shifts), gt_dev, adam_start, sr_types)
         return self._finish(res)
 
     def submit_image(self, image_dev, angles, shifts, gt_dev=None, adam_start=None,
@@ -114,7 +129,7 @@ class HotPath:
         ready.record(main)
         with torch.cuda.stream(self._side):
             self._side.wait_event(ready)
-            res = self._stage_sr(res, y, ymax, angles, shifts, gt_dev, adam_start, sr_types)
+            res = self._stage_sr(res, y, ymax, angles, self._sr_frame(image_dev, shifts), gt_dev, adam_start, sr_types)
             done = torch.cuda.Event()
             done.record(self._side)
         for t in [y, ymax] + [v for v in res.values() if isinstance(v, torch.Tensor)]:
@@ -134,7 +149,7 @@ class HotPath:
         stream.wait_stream(torch.cuda.current_stream())        # inputs prepared on the caller's stream
         with torch.cuda.stream(stream):
             res, y, ymax = self._stage_model(image_dev, angles, shifts, None, want_standard, lane=lane)
-            res = self._stage_sr(res, y, ymax, angles, shifts, gt_dev, adam_start, sr_types)
+            res = self._stage_sr(res, y, ymax, angles, self._sr_frame(image_dev, shifts), gt_dev, adam_start, sr_types)
             done = torch.cuda.Event()
             done.record(stream)
         return _Pending(self, res, done, keep=(y, ymax, gt_dev, image_dev))

@@ -64,15 +64,16 @@ def create_augmented_copies_chunked(image, num_aug, angle_max, shift_max, chunk_
     return np.concatenate(chunks, axis=0), angles, shifts
 
 
-def output_processing(predictions, filter_class_id, mode):
+def output_processing(predictions, filter_class_id, mode, out=None, out_max=None):
     """predictions [N,h,w,C] device tensor -> (class_masks [N,h,w], max_masks [N,h,w] | None), device.
-    argmax / slice / slice_max of augmentation_utils.py:80-115."""
+    argmax / slice / slice_max of augmentation_utils.py:80-115.  out / out_max: optional [N,h,w] destinations (the
+    rows of a per-image stack that is filled forward batch by forward batch)."""
     predictions = predictions.contiguous()
     if mode == "slice_max":
-        return ops.opm_slice_max(predictions, filter_class_id)
+        return ops.opm_slice_max(predictions, filter_class_id, out=out, out_max=out_max)
     if mode == "slice":
-        return ops.opm_slice(predictions, filter_class_id, 0.0, 1.0), None
-    return ops.opm_argmax(predictions, filter_class_id), None        # any other string = argmax, like the reference
+        return ops.opm_slice(predictions, filter_class_id, 0.0, 1.0, out=out), None
+    return ops.opm_argmax(predictions, filter_class_id, out=out), None        # any other string = argmax, like the reference
 
 
 def feature_maps_on_device(image_dev, model, filter_class_id, mode, angles, shifts, batch_size=16, profile=None):

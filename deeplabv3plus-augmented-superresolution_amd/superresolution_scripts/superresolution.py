@@ -166,8 +166,22 @@ class Superresolution:
         if self.num_iter == 0:
             return x, [None] * b
         state = self.optimizer.optimizer
-        x, terms = ops.sr_solve(x, copies, rot, tr, irot, itr, ops.to_device(alphas, device=dev), self._lambdas,
-                                want_loss=True, cfg=state.config(use_btv=self.use_BTV), slot_init=state.slot_init)
+        alphas_dev = ops.to_device(alphas, device=dev)
+        kw = dict(want_loss=True, cfg=state.config(use_btv=self.use_BTV), slot_init=state.slot_init)
+        if not self.verbose:
+            return ops.sr_solve(x, copies, rot, tr, irot, itr, alphas_dev, self._lambdas, **kw)
+        # superresolution.py:130-131 prints the loss of iteration i (evaluated before that iteration's update) for
+        # i % 10 == 0 and for the last one.  The solver reports the loss of the LAST iteration of a call, so the solve is
+        # cut after each printing iteration; the slots and the workspace carry over (same updates as one call).
+        carry, first, terms = {}, 0, None
+        for i in range(self.num_iter):
+            if i % 10 == 0 or i == self.num_iter - 1:
+                x, terms = ops.sr_solve(x, copies, rot, tr, irot, itr, alphas_dev[first:i + 1].contiguous(), self._lambdas,
+                                        state=carry, **kw)
+                first = i + 1
+                for bi, t in enumerate(terms.cpu().numpy()):
+                    tag = f"[image {bi}] " if b > 1 else ""
+                    print(f"{tag}{i + 1}/{self.num_iter} -- loss = {self._loss_from_terms(t)}")
         return x, terms
 
     def augmented_superresolution(self, augmented_copies, angles, shifts):
@@ -179,8 +193,6 @@ class Superresolution:
         a, s = self._batchify(angles, shifts)
         x, terms = self.augmented_superresolution_batch(y, a, s)
         loss = self._loss_from_terms(terms.cpu().numpy()[0]) if isinstance(terms, torch.Tensor) else None
-        if self.verbose and loss is not None:
-            print(f"{self.num_iter}/{self.num_iter} -- loss = {loss}")
         return x[0].cpu().numpy()[..., None], loss
 
     # -- superresolution.py:139-161 ---------------------------------------------------------------------

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define ASR_ABI_VERSION 1
+#define ASR_ABI_VERSION 2
 
 #define ASR_OK 0
 #define ASR_ERR_INVALID_ARG (-1)
@@ -100,6 +100,8 @@ int asr_sr_backward_adam_f32(const float* x, float* x_new, const float* resid, c
 int asr_sr_loss_terms_f64(const float* x, const float* resid, double* terms, int batch, int n, int H, int W, int h,
                           int w, asr_stream_t stream);
 
+/* Bytes of caller-owned workspace asr_sr_solve_f32 needs (residuals, the ping-pong x, the running data-term sum and the
+ * zero-bordered gradient planes of one chunk of copies; library default chunking, see asr_sr_config.plane_chunk). */
 size_t asr_sr_solve_workspace_bytes(int batch, int n, int H, int W, int h, int w);
 
 /* The whole loop of augmented_superresolution (superresolution.py:120-135): num_iter x
@@ -142,6 +144,9 @@ typedef struct asr_sr_config {
     int prior;         /* ASR_PRIOR_TV: tf.image.image_gradients TV; ASR_PRIOR_BTV: bilateral_tv */
     float btv_alpha;   /* bilateral_tv(alpha=0.6, ...) */
     int btv_shift;     /* bilateral_tv(shift_factor=2): pairs (h, v), h in [-s, s], v in [0, s]; 1 <= s <= 4 */
+    int plane_chunk;   /* asr_sr_solve_*: copies whose per-copy gradient planes are alive at once (a K_gt + K_bwd launch pair
+                        * per chunk, the data-term sum carried across in copy order: results do not depend on it).
+                        * 0 = library default (even split into chunks of <= 32 copies); >= n = all copies at once. */
 } asr_sr_config;
 
 /* asr_sr_backward_adam_f32 with the update rule and prior of `cfg` (host pointer, read during the call). */
@@ -154,6 +159,9 @@ int asr_sr_backward_cfg_f32(const float* x, float* x_new, const float* resid, co
 /* asr_sr_loss_terms_f64 with terms[b][1] = the prior selected by cfg (TV or bilateral TV). */
 int asr_sr_loss_terms_cfg_f64(const float* x, const float* resid, double* terms, int batch, int n, int H, int W,
                               int h, int w, const asr_sr_config* cfg, asr_stream_t stream);
+
+/* asr_sr_solve_workspace_bytes for asr_sr_solve_cfg_f32 with this cfg (its plane_chunk decides the size). */
+size_t asr_sr_solve_workspace_bytes_cfg(int batch, int n, int H, int W, int h, int w, const asr_sr_config* cfg);
 
 /* asr_sr_solve_f32 with the update rule and prior of `cfg`. */
 int asr_sr_solve_cfg_f32(float* x, const float* y, const float* rot_tf, const float* trans_tf, const float* inv_rot_tf,
@@ -344,8 +352,10 @@ int asr_dwconv3x3_nhwc_f32(const float* x, const float* w, const float* bias, fl
                            int ldx, int ldy, int pre_relu, int post_relu, int mode, asr_stream_t stream);
 
 /* The three dilated depthwise convs of the ASPP (aspp1/2/3_depthwise + BN + ReLU, model.py:212-221)
- * fused: the input plane is staged in LDS once and read by all three rates.  w3 [3,3,3,c] (branch
- * major), bias3 [3,c]; stride 1, 'same' padding; h*w*128 bytes must fit the 160 KB LDS. */
+ * fused: each residue class of the plane modulo g = gcd(rates) -- on which the dilated taps close -- is staged in LDS
+ * once and read by all three rates (input read from HBM once, any plane size).  w3 [3,3,3,c] (branch major),
+ * bias3 [3,c]; stride 1, 'same' padding; ceil(h/g) * ceil(w/g) * 128 bytes must fit the 160 KB LDS (ASR_ERR_UNSUPPORTED
+ * otherwise: run asr_dwconv3x3_nhwc_f32 per branch). */
 int asr_aspp_dwconv3_nhwc_f32(const float* x, const float* w3, const float* bias3, float* y0, float* y1, float* y2,
                               int batch, int h, int w, int c, int rate0, int rate1, int rate2, int ldx, int ldy,
                               int pre_relu, int post_relu, asr_stream_t stream);

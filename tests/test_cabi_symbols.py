@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol(lib):
         assert hasattr(lib, name), f"{name} declared in include/asr_hip.h but not exported"
     # and the ctypes signature table covers the header one-to-one
     assert sorted(_lib.SIGNATURES) == declared
-    assert lib.asr_abi_version() == 1
+    assert lib.asr_abi_version() == _lib.ABI_VERSION == 2
     assert lib.asr_target_arch() == b"gfx950"
 
 
@@ -41,7 +41,15 @@ def test_argument_validation_needs_no_gpu(lib):
     assert rc == -1 and b"null pointer" in lib.asr_last_error()
     rc = lib.asr_pwconv_packed_floats(728, 728)
     assert rc == 736 * 768
-    assert lib.asr_sr_solve_workspace_bytes(2, 3, 8, 8, 4, 4) == 4 * (2 * 3 * 16 + 2 * 64 + (2 * 3 + 2) * (8 + 4) * (8 + 8))
+    # residuals + ping-pong x + running data-term sum + bordered planes (one chunk of copies + x per image)
+    assert lib.asr_sr_solve_workspace_bytes(2, 3, 8, 8, 4, 4) == 4 * (2 * 3 * 16 + 2 * 2 * 64 + (2 * 3 + 2) * (8 + 4) * (8 + 8))
+    import ctypes as C
+    from asr_amd import ops
+    per = lambda chunk: 4 * (100 * 16 + 2 * 64 + (chunk + 1) * (8 + 4) * (8 + 8))
+    assert lib.asr_sr_solve_workspace_bytes(1, 100, 8, 8, 4, 4) == per(25)            # default: 4 chunks of 25 (<= 32)
+    assert lib.asr_sr_solve_workspace_bytes_cfg(1, 100, 8, 8, 4, 4, C.byref(ops.sr_config(plane_chunk=100))) == per(100)
+    assert lib.asr_sr_solve_workspace_bytes_cfg(1, 100, 8, 8, 4, 4, C.byref(ops.sr_config(plane_chunk=7))) == per(7)
+    assert lib.asr_sr_solve_workspace_bytes_cfg(1, 200, 8, 8, 4, 4, C.byref(ops.sr_config())) == 4 * (200 * 16 + 2 * 64 + (29 + 1) * 12 * 16)
 
 
 def test_product_refuses_cpu_tensors(lib):

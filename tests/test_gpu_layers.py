@@ -253,18 +253,30 @@ def test_dwconv_matches_conv2d(dev, h, w_, c, stride, rate, pre, post, direct):
     np.testing.assert_allclose(got, ref, rtol=1e-5, atol=2e-5)
 
 
-def test_aspp_fused_three_rates(dev):
-    """aspp1-3 depthwise (rates 6/12/18, BN folded, ReLU after) from one LDS-resident plane."""
+@pytest.mark.parametrize("h,w_,c,rates", [
+    (32, 32, 256, (6, 12, 18)),      # the OS-16 map of a 512 x 512 input: one column-phase group per row phase
+    (16, 24, 72, (6, 12, 18)),       # ragged: phases of 2-3 rows, c not a multiple of 32
+    (64, 64, 96, (6, 12, 18)),       # BASELINE configs[4] (1024 x 1024 input): 11-row phases, two column-phase groups
+    (64, 64, 64, (12, 24, 36)),      # OS 8 (model.py:42-47)
+    (33, 45, 40, (2, 4, 6)),         # odd sizes: the last row / column phases are one line shorter
+    (20, 28, 32, (1, 2, 3)),         # period 1: the whole plane is one phase
+    (8, 8, 32, (6, 12, 18)),         # rates beyond the plane: only the centre tap is ever inside
+])
+def test_aspp_fused_three_rates(dev, h, w_, c, rates):
+    """aspp1-3 depthwise (BN folded, ReLU after, model.py:212-221) from LDS-resident phases of the plane (residue classes
+    modulo gcd(rates)), any plane size."""
     from asr_amd import ops
     rng = np.random.default_rng(15)
-    for (h, w_, c) in ((32, 32, 256), (16, 24, 72)):
-        x = _rand(rng, 2, h, w_, c)
-        k3 = _rand(rng, 3, 3, 3, c, scale=0.3)
-        b3 = _rand(rng, 3, c)
-        outs = ops.aspp_dwconv3(ops.to_device(x), ops.to_device(k3), ops.to_device(b3), rates=(6, 12, 18))
-        for i, r in enumerate((6, 12, 18)):
-            ref = _dw_ref(x, k3[i], b3[i], 1, r, (r, r, r, r), False, True)
-            np.testing.assert_allclose(outs[i].cpu().numpy(), ref, rtol=1e-5, atol=2e-5)
+    x = _rand(rng, 2, h, w_, c)
+    k3 = _rand(rng, 3, 3, 3, c, scale=0.3)
+    b3 = _rand(rng, 3, c)
+    outs = ops.aspp_dwconv3(ops.to_device(x), ops.to_device(k3), ops.to_device(b3), rates=rates)
+    for i, r in enumerate(rates):
+        ref = _dw_ref(x, k3[i], b3[i], 1, r, (r, r, r, r), False, True)
+        np.testing.assert_allclose(outs[i].cpu().numpy(), ref, rtol=1e-5, atol=2e-5)
+    pre = ops.aspp_dwconv3(ops.to_device(x), ops.to_device(k3), ops.to_device(b3), rates=rates, pre_relu=True, post_relu=False)
+    ref = _dw_ref(x, k3[1], b3[1], 1, rates[1], (rates[1],) * 4, True, False)
+    np.testing.assert_allclose(pre[1].cpu().numpy(), ref, rtol=1e-5, atol=2e-5)
 
 
 def test_gap_and_resize(dev):
@@ -329,13 +341,15 @@ def test_presplit_sepconv_matches_the_f32_handoff(dev, c, n, hw, stride, rate):
     assert float(rec[:, c:].abs().max()) == 0.0 if chunks * 32 > c else True
 
 
-def test_aspp_split_operands_match_the_f32_outputs(dev):
-    """asr_aspp_dwconv3_nhwc_split_f16 at the product shape (32 x 32 x 2048, rates 6 / 12 / 18, model.py:212-221): the
-    split-f16 chunks it hands to the three pointwise GEMMs reproduce the f32 outputs of asr_aspp_dwconv3_nhwc_f32 to
-    2^-22, and the GEMM on them stays f32-grade against the float64 product."""
+@pytest.mark.parametrize("hw", [32, 64])
+def test_aspp_split_operands_match_the_f32_outputs(dev, hw):
+    """asr_aspp_dwconv3_nhwc_split_f16 at the product shapes (32 x 32 x 2048 for 512 x 512 inputs, 64 x 64 x 2048 for the
+    1024 x 1024 inputs of BASELINE configs[4]; rates 6 / 12 / 18, model.py:212-221): the split-f16 chunks it hands to the
+    three pointwise GEMMs reproduce the f32 outputs of asr_aspp_dwconv3_nhwc_f32 to 2^-22, and the GEMM on them stays
+    f32-grade against the float64 product."""
     from asr_amd import ops
     rng = np.random.default_rng(77)
-    b, hw, c, n = 2, 32, 2048, 256
+    b, c, n = 2, 2048, 256
     x = ops.to_device(_rand(rng, b, hw, hw, c))
     w3 = ops.to_device(_rand(rng, 3, 3, 3, c, scale=0.3))
     b3 = ops.to_device(_rand(rng, 3, c, scale=0.1))

@@ -108,3 +108,30 @@ def test_module_level_bilateral_tv_matches_oracle(dev):
     a, b2 = bilateral_tv(img[0, :, :, 0]), bilateral_tv(img)      # float64 atomics: the summation order is not fixed
     assert abs(a - b2) <= 1e-12 * abs(b2)
     assert su.check_hdf5_validity is su.check_validity
+
+
+def test_verbose_prints_the_reference_loss_lines_and_changes_no_update(dev, capsys):
+    """superresolution.py:130-131: with verbose the loss of iteration i is printed for i % 10 == 0 and for the last
+    iteration, as "{i+1}/{num_iter} -- loss = ...".  The solver is cut into several calls for that; the result must be
+    the single-call result bit for bit, and the printed values the oracle's."""
+    import re
+    H, h, n, iters = 64, 16, 6, 23
+    y, angs, shs = _sr_problem(12, 1, n, H, h)
+    quiet, ref_sr = _pair("adam", iters=iters, n=n, H=H, h=h, amsgrad=True)
+    loud, _ = _pair("adam", iters=iters, n=n, H=H, h=h, amsgrad=True)
+    loud.verbose = True
+    ref_sr.verbose = True
+    a, loss_a = quiet.augmented_superresolution(y[0][..., None], angs[0], shs[0])
+    capsys.readouterr()
+    b, loss_b = loud.augmented_superresolution(y[0][..., None], angs[0], shs[0])
+    got_lines = capsys.readouterr().out.strip().splitlines()
+    ref_sr.augmented_superresolution(y[0][..., None], angs[0], shs[0])
+    ref_lines = capsys.readouterr().out.strip().splitlines()
+    assert np.array_equal(a, b) and loss_a == loss_b
+    pat = re.compile(r"^(\d+)/(\d+) -- loss = (\S+)$")
+    got = [pat.match(l).groups() for l in got_lines]
+    ref = [pat.match(l).groups() for l in ref_lines]
+    assert [g[:2] for g in got] == [r[:2] for r in ref] == [(str(i + 1), str(iters)) for i in (0, 10, 20, 22)]
+    for g, r in zip(got, ref):
+        assert abs(float(g[2]) - float(r[2])) <= 1e-4 * abs(float(r[2]))
+    assert loud.optimizer.optimizer.iterations == quiet.optimizer.optimizer.iterations == iters

@@ -253,6 +253,41 @@ def test_sr_solve_two_kernel_backward_is_bit_identical_to_fused(dev, H, h):
     assert torch.equal(x_solve, xd)
 
 
+@pytest.mark.parametrize("n,H,h", [(70, 128, 32), (37, 64, 32)])
+def test_sr_solve_does_not_depend_on_the_plane_chunking(dev, n, H, h):
+    """The solver keeps the per-copy gradient planes of at most asr_sr_config.plane_chunk copies alive at once (default: an
+    even split into chunks of <= 32) and carries the data-term sum across the chunks in copy order: the same float32
+    additions as one pass over all copies, so x, m, v and the loss terms are bit-identical for every chunking --
+    all copies at once (round 2's form), the default (70 -> 3 x 24 with a ragged tail of 22; 37 -> 19 + 18), 8 (multiples
+    of the gather's unroll), 5 (the <8 and <4 tails) and 1."""
+    from asr_amd import _lib, ops, transforms as T
+    b, iters = 2, 3
+    y, angs, shs = _sr_problem(21, b, n, H, h)
+    lam = (1.0, 0.3, 0.7, 0.05)
+    rot, tr, irot, itr = _dev_tfs(angs, shs, H)
+    yd = ops.to_device(y)
+    b1, b2, eps = np.float32(0.9), np.float32(0.999), np.float32(1e-7)
+    alphas = np.zeros((iters, b), np.float32)
+    for it in range(iters):
+        alphas[it, :] = T.adam_alpha(np.float32(1e-3), b1, b2, it + 1)
+    ad = ops.to_device(alphas)
+
+    def run(chunk):
+        cfg = ops.sr_config(_lib.OPT_ADAM, True, np.float32(1) - b1, np.float32(1) - b2, eps, plane_chunk=chunk)
+        st = {}
+        x, terms = ops.sr_solve(ops.sr_init_target(yd, (H, H)), yd, rot, tr, irot, itr, ad, lam, cfg=cfg, state=st)
+        return x, terms, st["m"], st["v"], st["vhat"]
+
+    ref = run(n)
+    legacy, _ = ops.sr_solve(ops.sr_init_target(yd, (H, H)), yd, rot, tr, irot, itr, ad, lam, np.float32(1) - b1,
+                             np.float32(1) - b2, eps, True, want_loss=False)           # asr_sr_solve_f32: default chunking
+    assert torch.equal(legacy, ref[0])
+    for chunk in (0, 8, 5, 1):
+        got = run(chunk)
+        for a, r in zip(got, ref):
+            assert torch.equal(a, r), chunk
+
+
 def test_mask_pipeline_entry_points(dev):
     """The per-image glue of HotPath as library kernels: global min-max normalisation of a mask stack
     (superres_utils.py:56-62,183-206), the fused standard-output mask (generate_standard_output.py:52-65 = Resizing +
