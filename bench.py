@@ -44,19 +44,18 @@ ANGLE_MAX = 0.15
 SHIFT_MAX = 80
 CLASS_ID = 8
 SR_ITERS = 50
-TH_FACTOR = 0.2
 F32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: FP32 matrix peak (spec), dense
 HBM_PEAK_GBS = 8000.0
 F16_MFMA_PEAK_TFLOPS = 2500.0     # dense f16/bf16 MFMA peak (spec)
 
 # BASELINE.json configs -> concrete synthetic workloads.  feat = img / 4 (DeepLabV3+ without final upsample).
 CONFIGS = {
-    1: dict(img=512, out=512, num_aug=100, mode="argmax", activation=None, batch=100, steps=64,
+    1: dict(img=512, out=512, num_aug=100, mode="argmax", activation=None, batch=100, steps=64, th_factor=0.2,
             what="BASELINE configs[1]: synthetic 512x512 images, num_aug=100, angle+-0.15 shift+-80, argmax OPM class 8"),
-    2: dict(img=512, out=512, num_aug=100, mode="slice", activation="softmax", batch=100, steps=64,
+    2: dict(img=512, out=512, num_aug=100, mode="slice", activation="softmax", batch=100, steps=64, th_factor=0.65,
             what="BASELINE configs[2]: synthetic 512x512 images, num_aug=100, angle+-0.15 shift+-80, softmax + slice OPM "
                  "(dense float map of class 8, per-copy min-max normalised)"),
-    4: dict(img=1024, out=512, num_aug=200, mode="argmax", activation=None, batch=50, steps=8,
+    4: dict(img=1024, out=512, num_aug=200, mode="argmax", activation=None, batch=50, steps=8, th_factor=0.2,
             what="BASELINE configs[4]: synthetic 1024x1024 images, num_aug=200 (one draw, forward batches of 50), "
                  "angle+-0.15 shift+-80 input px (x0.5 in the 512x512 SR frame), argmax OPM class 8, model output 256x256, "
                  "2x SR"),
@@ -218,12 +217,12 @@ def parity(sample, cfg, model, make_sr, class_id, dev):
     up = tf_ops.resize_bilinear(ref[:1], (out, out)).numpy()[0]
     gt = np.where(up.argmax(-1) == class_id, class_id, 0).astype(np.int32)
     sr = make_sr(sample["iters"], n)
-    path = HotPath(model, sr, class_id=class_id, mode=cfg["mode"], th_factor=TH_FACTOR, batch_size=n)
+    path = HotPath(model, sr, class_id=class_id, mode=cfg["mode"], th_factor=cfg["th_factor"], batch_size=n)
     res = path.run_image(ops.to_device(sample["img"], device=dev), sample["angles"], sample["shifts"],
                          gt_dev=ops.to_device(gt, torch.int32, device=dev), adam_start=0)
     deltas, agree = {}, {}
     for t in ("aug", "max", "mean"):
-        o_mask = o_sr.threshold_image(sample["targets"][t], class_id, th_factor=TH_FACTOR)[..., 0]
+        o_mask = o_sr.threshold_image(sample["targets"][t], class_id, th_factor=cfg["th_factor"])[..., 0]
         h_mask = res[t].cpu().numpy()
         agree[t] = float((o_mask == h_mask).mean())
         o_iou = o_aug.compute_IoU(gt, o_mask, img_size=(out, out), class_id=class_id)
@@ -323,7 +322,7 @@ class Workload:
         self.model = DeeplabModel(weights, (self.img, self.img, 3), 21, final_upsample=False,
                                   last_activation=cfg["activation"], precision=precision)
         self.path = HotPath(self.model, self.make_sr(SR_ITERS, self.num_aug), class_id=CLASS_ID, mode=cfg["mode"],
-                            th_factor=TH_FACTOR, batch_size=self.batch)
+                            th_factor=cfg["th_factor"], batch_size=self.batch)
         img0 = ops.to_device(synth_image(np.random.default_rng(1234), self.img), device=dev)
         if bias_shift is None:
             bias_shift = calibrate_class_bias(self.model, img0, CLASS_ID, batch=self.batch)
@@ -559,6 +558,7 @@ def measure(cfg_id, args, rank, world, dev, weights, steps, warmup, images=None,
             "images_per_gpu": k_rank, "images_total": timed_count, "num_aug": wl.num_aug, "sr_iters": SR_ITERS,
             "forward_batch": wl.batch, "input": f"{wl.img}x{wl.img}", "sr": f"{wl.feat}x{wl.feat} -> {wl.out}x{wl.out}",
             "opm": cfg["mode"] + (" on softmax probabilities" if cfg["activation"] else ""),
+            "th_factor": cfg["th_factor"],      # test_SR.py:44 (0.2) for the argmax masks, SR_single_class.py:32 (0.65) for float maps
             "parallelism": (f"images sharded over {world} GPU(s) (image g on rank g mod {world}), one all-gather of IoU "
                             "records"),
             "overlap": ("SR stage of image i on a side HIP stream under the forward pass of image i+1" if args.overlap else

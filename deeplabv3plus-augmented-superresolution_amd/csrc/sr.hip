@@ -771,13 +771,19 @@ dim3 gr_grid(const SrDims& d, int cn) {
     return dim3((unsigned)asr_cdiv(d.W, 64), (unsigned)asr_cdiv(d.H, 4 * kGrRows), (unsigned)(d.batch * cn));
 }
 // Copies whose gradient planes are alive at once.  The planes (1.07 MB each at 512 x 512) are written by K_gt and read
-// back by K_bwd in the same iteration; all N at once is 107 MB at N = 100 and 214 MB per image at N = 200 (two images in
-// flight: past the 256 MB Infinity Cache).  <= 32 copies keep <= 35 MB live per image.  Even split of n into the fewest
-// such chunks; cfg->plane_chunk overrides (>= n: everything in one chunk, the round-2 form).
-constexpr int kPlaneChunkMax = 32;
-int sr_plane_chunk(int n, int requested) {
+// back by K_bwd in the same iteration: 107 MB at N = 100, 214 MB at N = 200.  Cutting them into chunks of <= 32 copies
+// (<= 35 MB live) was measured SLOWER on every shape and lane count (profiles/r03_sr_plane_chunk_experiment.txt: N = 100
+// 99 -> 127 us per iteration, N = 200 314 -> 348 us, two solves in flight 614 -> 694 us): each extra launch pair costs
+// more than the Infinity Cache misses it avoids, and the fabric counters see the planes either way.  The library default
+// therefore keeps all copies in one chunk while the planes stay under kPlaneBytesMax per call and splits evenly beyond
+// (a bound on the workspace, not a speed-up); cfg->plane_chunk overrides.
+constexpr size_t kPlaneBytesMax = (size_t)1 << 30;
+int sr_plane_chunk(int batch, int n, int H, int W, int requested) {
     if (requested > 0) return requested < n ? requested : n;
-    const int chunks = (n + kPlaneChunkMax - 1) / kPlaneChunkMax;
+    const size_t per_copy = sizeof(float) * (size_t)batch * sr_gr_plane_elems(H, W);
+    const size_t fit = kPlaneBytesMax / per_copy > 0 ? kPlaneBytesMax / per_copy : 1;
+    if ((size_t)n <= fit) return n;
+    const int chunks = (int)(((size_t)n + fit - 1) / fit);
     return (n + chunks - 1) / chunks;
 }
 size_t sr_workspace_bytes(int batch, int n, int H, int W, int h, int w, int chunk) {
@@ -921,11 +927,11 @@ extern "C" int asr_sr_loss_terms_f64(const float* x, const float* resid, double*
 }
 
 extern "C" size_t asr_sr_solve_workspace_bytes(int batch, int n, int H, int W, int h, int w) {
-    return sr_workspace_bytes(batch, n, H, W, h, w, sr_plane_chunk(n, 0));
+    return sr_workspace_bytes(batch, n, H, W, h, w, sr_plane_chunk(batch, n, H, W, 0));
 }
 
 extern "C" size_t asr_sr_solve_workspace_bytes_cfg(int batch, int n, int H, int W, int h, int w, const asr_sr_config* cfg) {
-    return sr_workspace_bytes(batch, n, H, W, h, w, sr_plane_chunk(n, cfg ? cfg->plane_chunk : 0));
+    return sr_workspace_bytes(batch, n, H, W, h, w, sr_plane_chunk(batch, n, H, W, cfg ? cfg->plane_chunk : 0));
 }
 
 // The whole optimisation loop of augmented_superresolution (superresolution.py:120-135) as one
@@ -949,7 +955,7 @@ extern "C" int asr_sr_solve_cfg_f32(float* x, const float* y, const float* rot_t
     rc = make_step("asr_sr_solve_cfg_f32", cfg, true, m, v, vhat, &st);
     if (rc != ASR_OK) return rc;
     ASR_REQUIRE(cfg->plane_chunk >= 0, "asr_sr_solve_cfg_f32: plane_chunk %d < 0", cfg->plane_chunk);
-    const int chunk = sr_plane_chunk(n, cfg->plane_chunk);
+    const int chunk = sr_plane_chunk(batch, n, H, W, cfg->plane_chunk);
     ASR_REQUIRE((int64_t)batch * chunk <= 65535, "asr_sr_solve_cfg_f32: batch*chunk=%lld exceeds 65535 (grid.z)", (long long)batch * chunk);
     const size_t need = sr_workspace_bytes(batch, n, H, W, h, w, chunk);
     if (workspace_bytes < need) {

@@ -113,7 +113,8 @@ def sr_forward_residual(x, y, rot_tf, trans_tf):
 def sr_config(optimizer=_lib.OPT_ADAM, flag=False, c0=0.0, c1=0.0, c2=0.0, use_btv=False, btv_alpha=0.6, btv_shift=2,
               plane_chunk=0):
     """asr_sr_config for the *_cfg entry points (meaning of c0..c2 per optimizer: include/asr_hip.h).  plane_chunk: copies
-    whose gradient planes the solver keeps alive at once (0 = library default, <= 32; results do not depend on it)."""
+    whose gradient planes the solver keeps alive at once (0 = library default: all of them up to 1 GiB of planes; results
+    do not depend on it)."""
     return _lib.SrConfig(int(optimizer), int(bool(flag)), float(c0), float(c1), float(c2),
                          _lib.PRIOR_BTV if use_btv else _lib.PRIOR_TV, float(btv_alpha), int(btv_shift), int(plane_chunk))
 

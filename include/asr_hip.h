@@ -146,7 +146,8 @@ typedef struct asr_sr_config {
     int btv_shift;     /* bilateral_tv(shift_factor=2): pairs (h, v), h in [-s, s], v in [0, s]; 1 <= s <= 4 */
     int plane_chunk;   /* asr_sr_solve_*: copies whose per-copy gradient planes are alive at once (a K_gt + K_bwd launch pair
                         * per chunk, the data-term sum carried across in copy order: results do not depend on it).
-                        * 0 = library default (even split into chunks of <= 32 copies); >= n = all copies at once. */
+                        * 0 = library default (all copies at once while the planes stay under 1 GiB per call -- the fastest
+                        * form on every measured shape --, an even split beyond); >= n = all copies at once. */
 } asr_sr_config;
 
 /* asr_sr_backward_adam_f32 with the update rule and prior of `cfg` (host pointer, read during the call). */

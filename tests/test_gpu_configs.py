@@ -1,7 +1,8 @@
 """The other BASELINE.json configurations as parity cases (configs[1] is the bench / test_gpu_model):
   configs[2]  softmax + slice OPM (dense per-class float maps)          -> parity with the oracle
   configs[2'] slice_max OPM (two SR solves per image, threshold class >= max)
-  configs[4]  1024x1024 inputs, num_aug = 200 (chunked), 2x SR (256 -> 512) -> properties at full size
+  configs[4]  1024x1024 inputs, num_aug = 200 (chunked), 2x SR (256 -> 512) -> properties at full size, the forward pass
+              (incl. the fused ASPP depthwise on the 64 x 64 map) and a 200-copy 2x SR solve against the oracle
 """
 import os
 
@@ -105,3 +106,71 @@ def test_config4_1024_inputs_200_copies_2x_sr(dev, synthetic):
     assert x.shape == (1, 512, 512) and torch.isfinite(x).all() and float(terms[0, 0]) > 0
     mx = sr.realign_batch(y, zeros_a, zeros_s, "max")
     assert torch.equal(mx, x0)
+
+
+def test_config4_forward_and_sr_match_the_oracle_at_full_size(dev, synthetic):
+    """configs[4] against the oracle at its real sizes.
+    (a) The 1024 x 1024 forward pass of two copies (the un-augmented image and copy 1 of the seed-1234 stream) after the
+        bench's class-bias calibration: logits within 2e-4 * max |logit|, argmax agreement >= 0.999 on a real class-8
+        region.  This pins every layer at the 4x larger maps -- in particular the three ASPP depthwise convs on the 64 x 64
+        map, which the fused phase kernel serves (csrc/dwconv.hip; round 2 fell back to three direct launches there).
+    (b) A 200-copy solve at f = 2 (256 x 256 -> 512 x 512, D = 2x2 box mean), shifts in the SR frame (x 0.5), two AMSGrad
+        iterations, against oracle.sr: x to 1e-6 (the same operation order; expected bit-identical), loss to 1e-4."""
+    import sys
+    from conftest import ROOT
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    import bench
+    from asr_amd import distributed as D, ops
+    from asr_amd.model import DeeplabModel
+    from asr_amd.superresolution_scripts import augmentation_utils as au
+    from asr_amd.superresolution_scripts.optimizer import Optimizer
+    from asr_amd.superresolution_scripts.superresolution import Superresolution
+    from oracle import tf_ops
+    size, cls, n = 1024, 8, 200
+    img = bench.synth_image(np.random.default_rng(1234), size)
+    img_dev = ops.to_device(img, device=dev)
+    model = DeeplabModel(synthetic, (size, size, 3), 21, final_upsample=False, last_activation=None)
+    delta = bench.calibrate_class_bias(model, img_dev, cls)
+    weights = bench.shifted_weights(synthetic, cls, delta)
+    angles, shifts = D.replay_augmentation_stream(1, n, 0.15, 80, seed=1234)[0]
+    idx = [0, 1]
+    copies = au.augment_on_device(img_dev, angles[idx], shifts[idx])
+    logits = model.predict_device(copies, batch_size=2).cpu().numpy()
+    tiled = torch.from_numpy(np.broadcast_to(img[None], (2, size, size, 3)).copy())
+    o_copies = tf_ops.translate(tf_ops.rotate(tiled, angles[idx]), shifts[idx]).numpy()
+    np.testing.assert_allclose(copies.cpu().numpy(), o_copies, rtol=0, atol=2e-6)
+    o_logits = OracleDeeplabV3Plus(weights).predict(o_copies, batch_size=1)
+    assert o_logits.shape == logits.shape == (2, 256, 256, 21)
+    np.testing.assert_allclose(logits, o_logits, rtol=0, atol=2e-4 * np.abs(o_logits).max())
+    frac = float((o_logits.argmax(-1) == cls).mean())
+    assert 0.05 < frac < 0.8, frac
+    assert float((logits.argmax(-1) == o_logits.argmax(-1)).mean()) >= 0.999
+
+    # (b) 200 LR masks at 256 x 256: the two real ones plus shifted / rotated blobs (cheap, structured), N = 200, f = 2
+    masks, _ = o_aug.opm(o_logits, cls, "argmax")
+    base = (np.stack(masks)[..., 0] / np.float32(cls)).astype(np.float32)              # {0, 1}, [2, 256, 256]
+    yy, xx = np.meshgrid(np.arange(256, dtype=np.float32), np.arange(256, dtype=np.float32), indexing="ij")
+    y = np.empty((n, 256, 256), np.float32)
+    rng = np.random.default_rng(5)
+    for i in range(n):
+        cy, cx, ry, rx = rng.uniform(90, 166), rng.uniform(90, 166), rng.uniform(40, 80), rng.uniform(40, 80)
+        blob = ((((yy - cy) / ry) ** 2 + ((xx - cx) / rx) ** 2) < 1).astype(np.float32)
+        y[i] = np.maximum(blob, base[i % 2] * 0.5)
+    sr_shifts = (shifts * np.float32(0.5)).astype(np.float32)
+    iters = 2
+    opt = Optimizer("adam", 1e-3, amsgrad=True, lr_scheduler=True, decay_steps=60, decay_rate=0.3)
+    o_opt = o_sr.Optimizer("adam", 1e-3, amsgrad=True, lr_scheduler=True, decay_steps=60, decay_rate=0.3)
+    sr = Superresolution(1.0, 0.3, 0.7, 0.0, num_iter=iters, num_aug=n, optimizer=opt, feature_size=(256, 256),
+                         output_size=(512, 512))
+    o_srobj = o_sr.Superresolution(1.0, 0.3, 0.7, 0.0, num_iter=iters, num_aug=n, optimizer=o_opt, feature_size=(256, 256),
+                                   output_size=(512, 512))
+    got, loss = sr.augmented_superresolution(y[..., None], angles, sr_shifts)
+    ref, ref_loss = o_srobj.augmented_superresolution(y[..., None], angles, sr_shifts)
+    d = np.abs(got - ref)
+    assert d.max() <= 1e-6, (d.max(), d.mean())
+    assert abs(loss - ref_loss) <= 1e-4 * abs(ref_loss)
+    for mode in ("max", "mean"):
+        g, _ = getattr(sr, f"{mode}_superresolution")(y[..., None], angles, sr_shifts)
+        r, _ = getattr(o_srobj, f"{mode}_superresolution")(y[..., None], angles, sr_shifts)
+        np.testing.assert_allclose(g, r, rtol=0, atol=2e-6)
