@@ -91,22 +91,22 @@ def adam_start_step(image_index, num_iter, mode="argmax"):
     return image_index * num_iter * (2 if mode == "slice_max" else 1)
 
 
-def all_gather_iou(local_indices, local_records, num_images, device=None):
-    """local_records: [n_local, 6] float64 IoUs of the images in local_indices.  Returns the full
-    [num_images, 6] table (NaN where no rank reported) on every rank via one all_gather."""
-    rec = np.asarray(local_records, dtype=np.float64).reshape(-1, len(IOU_FIELDS))
+def all_gather_rows(local_indices, local_rows, num_rows, width, device=None):
+    """local_rows: [n_local, width] float64 rows of the global indices local_indices.  Returns the full
+    [num_rows, width] table (NaN where no rank reported) on every rank via ONE all_gather of equal-sized slots."""
+    rec = np.asarray(local_rows, dtype=np.float64).reshape(-1, width)
     idx = np.asarray(local_indices, dtype=np.int64)
     assert rec.shape[0] == idx.shape[0]
-    table = np.full((num_images, len(IOU_FIELDS)), np.nan)
+    table = np.full((num_rows, width), np.nan)
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         table[idx] = rec
         return table
     world = dist.get_world_size()
-    cap = -(-num_images // world)                       # equal-sized slots: ceil(images / world)
+    cap = -(-num_rows // world)                       # equal-sized slots: ceil(rows / world)
     if device is None:
         device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
     device = collective_device(device)
-    slot = torch.full((cap, 1 + len(IOU_FIELDS)), -1.0, dtype=torch.float64)
+    slot = torch.full((cap, 1 + width), -1.0, dtype=torch.float64)
     slot[:len(idx), 0] = torch.from_numpy(idx.astype(np.float64))
     slot[:len(idx), 1:] = torch.from_numpy(rec)
     slot = slot.to(device)
@@ -117,6 +117,12 @@ def all_gather_iou(local_indices, local_records, num_images, device=None):
         valid = g[:, 0] >= 0
         table[g[valid, 0].astype(np.int64)] = g[valid, 1:]
     return table
+
+
+def all_gather_iou(local_indices, local_records, num_images, device=None):
+    """local_records: [n_local, 6] float64 IoUs of the images in local_indices.  Returns the full
+    [num_images, 6] table (NaN where no rank reported) on every rank via one all_gather."""
+    return all_gather_rows(local_indices, local_records, num_images, len(IOU_FIELDS), device)
 
 
 def mean_ious(table):

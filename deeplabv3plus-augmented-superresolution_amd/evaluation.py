@@ -25,32 +25,47 @@ def interchange_files(root_dir):
         stem = os.path.basename(path).split(".")[0]
         return (0, int(stem), path) if stem.isdigit() else (1, 0, path)
 
-    return sorted(found, key=key)
+    # one file per image: a folder that holds both 7.hdf5 and 7.npz (two runs of stage 1 with different ASR_DATA_EXT)
+    # must not evaluate image 7 twice -- the first extension of DATA_EXTS wins (.hdf5, the reference's format)
+    best = {}
+    for path in sorted(found, key=lambda q: (key(q)[:2], DATA_EXTS.index(next(e for e in DATA_EXTS if q.endswith(e))), q)):
+        best.setdefault((os.path.dirname(path), os.path.basename(path).split(".")[0]), path)
+    return sorted(best.values(), key=key)
 
 
 def evaluate_precomputed(sr, paths, gt_dir, standard_dir=None, num_aug=100, class_id=8, th_factor=0.65,
                          img_size=(512, 512), out_dir=None, rank=0, world=1, save_final_output=False):
-    """Returns the [len(paths), 6] IoU table (distributed.IOU_FIELDS order) on every rank; the row of an invalid file is
-    all-NaN and ``valid_rows`` / ``mean_over_valid`` drop it, like the reference's ``continue`` (SR_single_class.py:85-90).
-    ``sr.optimizer``'s global step counter is set per image to what the reference's sequential loop would have reached:
-    num_iter * solves_per_image * (number of VALID images before it) -- a skipped file runs no solve there, so it does not
-    advance the counter here either.  Validity is a header check every rank can afford for all files, so sharding does not
-    change any update."""
+    """Returns (table, valid) on every rank: the [len(paths), 6] IoU table (distributed.IOU_FIELDS order) and the bool
+    mask of the files that were evaluated.  The row of an invalid file is all-NaN and never enters a mean, like the
+    reference's ``continue`` (SR_single_class.py:85-90); a VALID image whose IoUs are NaN (class absent from both masks)
+    keeps its row, so the mean over the valid rows is NaN exactly when the reference's np.mean is.
+
+    Validity is what ``load_SR_data`` itself decides -- each rank loads the files of its own shard once (no second
+    probe, no rank opens another rank's files) -- and is all-gathered BEFORE any solve, together with the number of
+    Adam solves each file will run (two for slice_max files: class map and max map).  ``sr.optimizer``'s global step
+    counter is then set per image to what the reference's sequential loop would have reached: num_iter * (solves of the
+    valid files before it); a skipped file runs no solve there, so it does not advance the counter here either, and
+    sharding changes no update."""
     mine = D.shard_indices(len(paths), rank, world)
-    valid = np.array([_is_valid(p, num_aug) for p in paths], dtype=bool)
-    before = np.concatenate([[0], np.cumsum(valid)[:-1]]) if len(paths) else np.zeros(0, int)
-    records = []
+    loaded, flags = {}, []
     for g in mine:
         try:
-            if not valid[g]:
-                raise Exception(f"File: {paths[g]} is invalid")
-            class_masks, max_masks, angles, shifts, filename = load_SR_data(paths[g], num_aug=num_aug)
+            loaded[g] = load_SR_data(paths[g], num_aug=num_aug)
+            flags.append([1.0, 2.0 if loaded[g][1] is not None else 1.0])
         except Exception:
             print(f"File: {paths[g]} is invalid, skipping...")
+            flags.append([0.0, 0.0])
+    status = D.all_gather_rows(mine, flags, len(paths), 2)                    # [files, (valid, solves)] on every rank
+    valid = np.nan_to_num(status[:, 0]) > 0.5
+    solves = np.where(valid, np.nan_to_num(status[:, 1]), 0.0).astype(np.int64)
+    before = np.concatenate([[0], np.cumsum(solves)[:-1]]) if len(paths) else np.zeros(0, np.int64)
+    records = []
+    for g in mine:
+        if not valid[g]:
             records.append([np.nan] * len(D.IOU_FIELDS))
             continue
-        sr.optimizer.optimizer.iterations = D.adam_start_step(int(before[g]), sr.num_iter,
-                                                              "slice_max" if max_masks is not None else "argmax")
+        class_masks, max_masks, angles, shifts, filename = loaded.pop(g)
+        sr.optimizer.optimizer.iterations = int(before[g]) * sr.num_iter
         true_mask = load_image(os.path.join(gt_dir, f"{filename}.png"), image_size=img_size, normalize=False, is_png=True,
                                resize_method="nearest")
         mm = max_masks if max_masks is not None else []
@@ -67,30 +82,19 @@ def evaluate_precomputed(sr, paths, gt_dir, standard_dir=None, num_aug=100, clas
                               compute_IoU(true_mask, out["aug"], img_size=img_size, class_id=class_id, include_bg=True),
                               compute_IoU(true_mask, out["max"], img_size=img_size, class_id=class_id),
                               compute_IoU(true_mask, out["mean"], img_size=img_size, class_id=class_id)])
-    return D.all_gather_iou(mine, records, len(paths))
+    return D.all_gather_iou(mine, records, len(paths)), valid
 
 
-def _is_valid(path, num_aug):
-    """Cheap validity probe every rank runs over ALL files: the file opens and every array dataset holds >= num_aug
-    entries (superres_utils.py:108-115).  HDF5 files are judged from their object headers alone (no dataset is read)."""
-    from . import hdf5_lite
-    from .superresolution_scripts.superres_utils import _open_SR_file, check_validity
-    try:
-        if str(path).endswith(".npz"):
-            return bool(check_validity(_open_SR_file(path), num_aug=num_aug))
-        shp = hdf5_lite.shapes(path)
-        return "class_masks" in shp and all(len(v) >= 1 and v[0] >= num_aug for k, v in shp.items()
-                                            if k in ("class_masks", "max_masks", "angles", "shifts"))
-    except Exception:
-        return False
-
-
-def valid_rows(table):
-    """Rows of images that were evaluated (an invalid interchange file leaves an all-NaN row)."""
+def valid_rows(table, valid=None):
+    """Rows of the images that were evaluated: by the explicit mask evaluate_precomputed returns; without one, every row
+    that is not all-NaN (a table from elsewhere)."""
     table = np.asarray(table, dtype=np.float64)
+    if valid is not None:
+        return table[np.asarray(valid, dtype=bool)]
     return table[~np.isnan(table).all(axis=1)]
 
 
-def mean_over_valid(table):
-    """The six means SR_single_class.py:129-134 prints: np.mean over the images that were not skipped."""
-    return D.mean_ious(valid_rows(table))
+def mean_over_valid(table, valid=None):
+    """The six means SR_single_class.py:129-134 prints: np.mean over the images that were not skipped (NaN where a valid
+    image has a NaN IoU, as there)."""
+    return D.mean_ious(valid_rows(table, valid))

@@ -1,8 +1,10 @@
 """SR glue with the reference's surface (superresolution_scripts/superres_utils.py):
 ``min_max_normalization`` (:56-62), ``threshold_image`` (:118-139), ``load_SR_data`` (:154-210),
-``compute_SR`` (:213-273) and ``check_hdf5_validity`` (:108-115).  The reference's dataset-list helpers (:9-53,
-:65-105, :142-151) are file plumbing outside the hot path and are not provided; the evaluation loop
-finds its interchange files itself (``asr_amd.evaluation.interchange_files``).  The interchange file is the reference's HDF5 file (same dataset and
+``compute_SR`` (:213-273) and ``check_hdf5_validity`` (:108-115), plus the thin host-side list helpers the reference's
+scripts import from this module (``get_img_paths`` :9-29, ``class_in_image`` :32-38, ``filter_images_by_class`` :41-53,
+``load_precomputed_images`` :65-78, ``get_precomputed_folders_path`` :81-90, ``list_precomputed_data_paths`` :93-105,
+``normalize_coefficients`` :142-151): pure file plumbing, no device work, kept so that code written against the
+reference's module still imports.  The interchange file is the reference's HDF5 file (same dataset and
 attribute names, written / read by ``hdf5_lite``: files from the reference's h5py writer load here and vice versa);
 an ``.npz`` with the same keys is accepted too (``ASR_DATA_EXT=.npz`` makes it the written format).
 """
@@ -17,6 +19,77 @@ from .. import _lib, hdf5_lite, ops
 
 DATA_EXT = os.environ.get("ASR_DATA_EXT", ".hdf5")          # what save_SR_data writes: ".hdf5" (reference) or ".npz"
 DATA_EXTS = (".hdf5", ".h5", ".npz")                         # what the readers accept
+
+
+# ---- list helpers (host only) ------------------------------------------------------------------------
+def _stem_as_int(path):
+    return int(os.path.basename(path).split(".")[0])
+
+
+def get_img_paths(image_list_path, image_folder, is_png=False, sort=True):
+    """One image id per line of ``image_list_path`` -> ``image_folder/<id>.jpg`` (``.png`` with is_png); ``sort`` orders
+    the result by the integer value of the id (VOC ids are integers)."""
+    suffix = ".png" if is_png else ".jpg"
+    with open(image_list_path) as fh:
+        ids = [line.rstrip() for line in fh]
+    paths = [os.path.join(image_folder, i + suffix) for i in ids]
+    return sorted(paths, key=_stem_as_int) if sort else paths
+
+
+def class_in_image(image_path, class_id, image_size=(512, 512)):
+    """Does the label map that belongs to ``image_path`` (same VOC tree: JPEGImages -> SegmentationClassAug, jpg -> png)
+    contain ``class_id``?  The map is resized with nearest neighbour like every label map of the path."""
+    from ..utils import load_image
+    label_path = image_path.replace("JPEGImages", "SegmentationClassAug").replace("jpg", "png")
+    labels = load_image(label_path, image_size=image_size, normalize=False, is_png=True, resize_method="nearest")
+    return bool((np.asarray(labels) == class_id).any())
+
+
+def filter_images_by_class(path_list, filter_class_id, num_images=None, image_size=(512, 512)):
+    """The paths whose label map contains ``filter_class_id``, in list order, at most ``num_images`` of them."""
+    limit = len(path_list) if num_images is None else num_images
+    kept = []
+    for path in path_list:
+        if len(kept) == limit:
+            break
+        if class_in_image(path, class_id=filter_class_id, image_size=image_size):
+            kept.append(path)
+    return kept
+
+
+def load_precomputed_images(img_folder):
+    """The PNG copies ``0.png, 1.png, ...`` of a pre-HDF5 output folder, in numeric order (its ``.npy`` side files are
+    not images)."""
+    from ..utils import load_image
+    numbers = sorted(int(name[:-len(".png")]) for name in os.listdir(img_folder) if ".npy" not in name)
+    return [load_image(os.path.join(img_folder, f"{k}.png"), normalize=False, is_png=True) for k in numbers]
+
+
+def get_precomputed_folders_path(root_dir, num_aug=100):
+    """Sub-folders of ``root_dir`` that are complete: ``num_aug`` copies plus the two side files (angles, shifts).
+    Incomplete ones are reported and left out."""
+    complete = []
+    for name in os.listdir(root_dir):
+        folder = os.path.join(root_dir, name)
+        if len(os.listdir(folder)) != num_aug + 2:
+            print(f"Skipped folder named {name} as it is not valid")
+            continue
+        complete.append(folder)
+    return complete
+
+
+def list_precomputed_data_paths(root_dir, sort=False):
+    """Every ``.hdf5`` interchange file below ``root_dir`` (os.walk order, or by integer stem with ``sort``).  The
+    evaluation loop of this package uses ``asr_amd.evaluation.interchange_files`` instead: one order on every rank,
+    ``.npz`` files too, one file per stem."""
+    found = [os.path.join(folder, f) for folder, _dirs, files in os.walk(root_dir) for f in files if f.endswith(".hdf5")]
+    return sorted(found, key=_stem_as_int) if sort else found
+
+
+def normalize_coefficients(coeff_dict):
+    """The same keys with the values scaled to sum to one."""
+    total = np.sum(list(coeff_dict.values()))
+    return {key: value / total for key, value in coeff_dict.items()}
 
 
 def min_max_normalization(image, new_min=0.0, new_max=255.0, global_min=None, global_max=None):

@@ -44,10 +44,10 @@ def main():
                          lambda_L1=HYPER["lambda_L1"], num_iter=HYPER["num_iter"], num_aug=args.num_aug,
                          optimizer=optimizer_obj, feature_size=(args.feature_size, args.feature_size))
     paths = interchange_files(args.data)[:args.num_samples]
-    table = evaluate_precomputed(sr, paths, args.gt, args.standard, num_aug=args.num_aug, class_id=args.class_id,
-                                 th_factor=args.th_factor, img_size=IMG_SIZE, out_dir=args.out, rank=rank, world=world)
+    table, valid = evaluate_precomputed(sr, paths, args.gt, args.standard, num_aug=args.num_aug, class_id=args.class_id,
+                                        th_factor=args.th_factor, img_size=IMG_SIZE, out_dir=args.out, rank=rank, world=world)
     if rank == 0:
-        m = mean_over_valid(table)
+        m = mean_over_valid(table, valid)
         print(f"Avg. Standard IoUs (No bg): {m['standard_single']},  Avg. Augmented SR IoUs (No bg): {m['aug_single']}")
         print(f"Avg. Standard IoUs (with bg): {m['standard_bg']},  Avg. Augmented SR IoUs (with bg): {m['aug_bg']}")
         print(f"Avg. Max SR IoUs: {m['max']}, Avg. Mean SR IoUs: {m['mean']}")

@@ -75,7 +75,7 @@ def test_save_and_load_SR_data_both_containers(tmp_path):
         got[ext] = su.load_SR_data(p, num_aug=3)
     for a, b in zip(got[".hdf5"], got[".npz"]):
         assert (a == b) if isinstance(a, str) else np.array_equal(a, b)
-    assert sorted(os.path.basename(p) for p in __import__("asr_amd.evaluation", fromlist=["x"]).interchange_files(str(tmp_path))) == ["7.hdf5", "7.npz"]
+    assert sorted(os.path.basename(p) for p in __import__("asr_amd.evaluation", fromlist=["x"]).interchange_files(str(tmp_path))) == ["7.hdf5"]          # one file per image: .hdf5 wins
 
 
 def test_keras_weight_file_layout():

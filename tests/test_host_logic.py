@@ -171,14 +171,34 @@ def test_evaluation_order_validity_and_means(tmp_path):
     (tmp_path / "d" / "11.hdf5").write_bytes(b"not an hdf5 file")
     paths = E.interchange_files(str(tmp_path))
     assert [os.path.basename(p) for p in paths] == ["9.hdf5", "10.hdf5", "11.hdf5", "100.hdf5", "2007_000032.hdf5"]
-    valid = [E._is_valid(p, 6) for p in paths]
+
+    def loads(p):
+        try:
+            su.load_SR_data(p, num_aug=6)
+            return True
+        except Exception:
+            return False
+
+    valid = [loads(p) for p in paths]
     assert valid == [True, True, False, False, True]          # 11: unreadable, 100: only 3 copies
     table = np.full((5, 6), np.nan)
     table[[0, 1, 4]] = [[0.5] * 6, [0.7] * 6, [0.9] * 6]
-    assert E.valid_rows(table).shape == (3, 6)
-    m = E.mean_over_valid(table)
+    assert E.valid_rows(table).shape == (3, 6) and E.valid_rows(table, valid).shape == (3, 6)
+    m = E.mean_over_valid(table, valid)
     assert abs(m["aug_single"] - 0.7) < 1e-12 and not any(np.isnan(v) for v in m.values())
     assert np.isnan(D.mean_ious(table)["aug_single"])         # the plain mean over all rows would be NaN
+    # a VALID image whose IoUs are all NaN (class absent from both masks) stays a row: the mean is NaN, as np.mean over
+    # the reference's lists would be -- with the explicit mask; NaN inference alone would drop it
+    table[1] = np.nan
+    assert np.isnan(E.mean_over_valid(table, valid)["aug_single"]) and E.valid_rows(table).shape == (2, 6)
+    # one file per image when a folder holds two container formats of the same stem
+    su.save_SR_data(str(tmp_path / "d" / "9"), masks, None, a, sh, "9", "argmax", 0.15, 80, ext=".npz")
+    assert [os.path.basename(p) for p in E.interchange_files(str(tmp_path))][:2] == ["9.hdf5", "10.hdf5"]
+    # the reference-named helpers are importable from the reference's module path
+    assert su.list_precomputed_data_paths(str(tmp_path), sort=False) and su.normalize_coefficients({"a": 1.0, "b": 3.0}) == {"a": 0.25, "b": 0.75}
+    lst = tmp_path / "ids.txt"
+    lst.write_text("12\n7\n")
+    assert su.get_img_paths(str(lst), "/x") == ["/x/7.jpg", "/x/12.jpg"] and su.get_img_paths(str(lst), "/x", is_png=True, sort=False)[0] == "/x/12.png"
 
 
 def test_bench_refuses_a_wrong_rank_count():

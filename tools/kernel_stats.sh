@@ -5,7 +5,7 @@ tag=${1:-stats}
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$tag -o $tag -- python3 bench.py --steps 8 --no-cpu-baseline --no-roofline > gpurun_out/prof_$tag.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$tag -o $tag -- python3 bench.py --steps 8 --no-cpu-baseline --no-roofline --no-f32-line --no-extra-configs > gpurun_out/prof_$tag.log 2>&1
 python3 - "$tag" <<'PY'
 import csv, glob, sys
 tag = sys.argv[1]
