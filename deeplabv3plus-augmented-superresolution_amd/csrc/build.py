@@ -18,7 +18,9 @@ LIB = os.path.join(PKG, "libasr_hip.so")
 # loops, a device synchronisation after every split-f16 launch) goes to its own object directory and library; select it at
 # run time with ASR_LIB=<path> (asr_amd/_lib.py).
 VARIANTS = {"phase": ["-DASR_GEMM_PHASE_PROFILE"],      # s_memtime stamps per phase of the GEMM K loops
-            "diag": ["-DASR_DIAG_KERNELS"]}                # extra experiment kernels (asr_diag_* entry points), no stamps
+            "diag": []}                                    # + csrc/diag/*.hip: earlier kernel forms (asr_diag_* entry points)
+# translation units that exist in one variant only (never in the product library)
+VARIANT_SOURCES = {"diag": [(os.path.join("diag", "gemm_diag.hip"), [])]}
 
 # (source, extra flags)
 SOURCES = [
@@ -31,7 +33,7 @@ SOURCES = [
     ("layers.hip", []),
     ("sepconv.hip", []),
 ]
-HEADERS = ["asr_common.h", "asr_warp_device.h", os.path.join("..", "..", "include", "asr_hip.h")]
+HEADERS = ["asr_common.h", "asr_warp_device.h", "gemm_common.h", os.path.join("..", "..", "include", "asr_hip.h")]
 COMMON = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
           "-x", "hip"]
 
@@ -78,9 +80,9 @@ def _build_locked(objdir, force, verbose, variant=""):
         force = True
     hdrs = [os.path.join(HERE, h) for h in HEADERS] + [os.path.abspath(__file__)]
     objs = []
-    for src, extra in SOURCES:
+    for src, extra in SOURCES + VARIANT_SOURCES.get(variant, []):
         s = os.path.join(HERE, src)
-        o = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
+        o = os.path.join(objdir, os.path.splitext(os.path.basename(src))[0] + ".o")
         objs.append(o)
         if force or _stale(o, [s] + hdrs):
             cmd = [hipcc] + COMMON + extra + extra_all + ["-c", s, "-o", o]

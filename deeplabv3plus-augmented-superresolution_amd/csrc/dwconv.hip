@@ -138,6 +138,11 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 #define ASR_DW_NT 1
 #endif
 constexpr bool kNtStores = ASR_DW_NT != 0;
+// Maps of up to this many output rows are walked in 16-row strips with 4 rows of input in flight and the activation
+// pattern compiled in; taller ones in 32-row strips with one row in flight (measured per map size).
+#ifndef ASR_DW_SMALL_MAX
+#define ASR_DW_SMALL_MAX 32
+#endif
 template <int R, int S, int SROWS, int PF, bool SPLIT, int ACT>
 __global__ __launch_bounds__(256) void dw_stream_full_kernel(DwArgs p, int tiles_x) {
     constexpr int WIN = 2 * R + 1;
@@ -431,7 +436,7 @@ __global__ __launch_bounds__(256) void dw_direct_kernel(DwArgs p) {
 template <int R, int S>
 int launch_stream(const DwArgs& p, hipStream_t s, bool split = false) {
     const int tiles_x = (int)asr_cdiv(p.w_out, SCOLS), chunks = (int)asr_cdiv(p.c, 64);
-    const int srows = p.h_out <= 32 ? 16 : 32;
+    const int srows = p.h_out <= ASR_DW_SMALL_MAX ? 16 : 32;
     const dim3 grid(tiles_x * chunks, (unsigned)asr_cdiv(p.h_out, srows), p.batch);
     // full strips (every layer of the net): the branch-free kernel; 4 rows in flight on the small OS16 maps (few waves
     // per image), 1 on the large ones (measured); the two activation patterns of the Xception sepconvs are

@@ -19,193 +19,9 @@
 //  * blockIdx -> tile mapping is XCD-aware: the tiles that share an A row-panel get
 //    consecutive logical ids, and logical ids are dealt so that consecutive ones share an XCD
 //    (private L2), using the bijective remap.
-#include "asr_common.h"
-#include <utility>
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
+#include "gemm_common.h"
 
 namespace {
-
-constexpr int BK = 32;
-
-struct PwArgs {
-    const float* x;
-    const float* wp;
-    const float* bias;
-    const float* res;
-    float* y;
-    long long M;
-    int K, N, Npad, Kpad;
-    int ldx, ldy, ldres;
-    int relu;
-    int tiles_n;
-    // row mapping: output row m = (b, oy, ox) of an h_out x w_out map
-    int taps;  // 1 = pointwise (optionally spatially subsampled), 9 = 3x3 implicit GEMM
-    int cin;   // channels per tap
-    int h_in, w_in, h_out, w_out, stride, pad, dil;
-};
-
-// ---- epilogue shared by the f32 and the split-f16 kernels ------------------------------------------
-// C/D map of every 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
-// The accumulators hold columns on lanes; writing them straight out would cost 16 dword stores per
-// 32x32 tile, each touching two 128-byte row pieces.  Instead every wave transposes its
-// (32 x TN*32) half-tile through its own slice of the (now idle) staging LDS and stores whole
-// 16-byte pieces: 16 lanes cover one 256-byte row segment, 4x fewer store instructions.
-// The caller guarantees (barrier) that no wave still reads the staging tiles.
-template <int WM, int WN, int TM, int TN, bool RES_AHEAD = false>
-__device__ __forceinline__ void pw_epilogue(const PwArgs& p, f32x16 (&acc)[TM][TN], float* smem, int tile_m, int tile_n,
-                                            int wave, int lane) {
-    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-    constexpr int WCOLS = TN * 32;                 // columns of the wave's sub-tile
-    constexpr int LPR = WCOLS / 4;                 // lanes per row in the read-back
-    constexpr int RPI = 64 / LPR;                  // rows per wave-instruction
-    const int wm = wave / WN, wn = wave % WN;
-    const int l32 = lane & 31, hh = lane >> 5;
-    float* const stage = smem + wave * (32 * WCOLS);
-    const bool vec_ok = ((p.N & 3) == 0) && ((p.ldy & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.y) & 15) == 0) &&
-                        (!p.res || (((p.ldres & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.res) & 15) == 0)));
-    const int n_wave = tile_n * BN + wn * WCOLS;
-    const int c4 = lane % LPR, r_in = lane / LPR;
-    const int n = n_wave + c4 * 4;
-    const bool res_vec = vec_ok && p.res != nullptr;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const long long m_base = (long long)tile_m * BM + (wm * TM + i) * 32;
-        // RES_AHEAD (kernels with registers to spare: the 256 x 256 LDS-DMA kernel): the residual pieces of this
-        // 32-row slab are requested before the accumulators go through the LDS (clamped addresses, no branch around the
-        // loads), so they arrive during the transposition instead of one waited-for round trip per piece in the store loop.
-        f32x4 rv[RES_AHEAD ? 32 / RPI : 1];
-        if (RES_AHEAD && res_vec) {
-            const float* rbase = p.res + (n < p.N ? n : 0);
-#pragma unroll
-            for (int q = 0; q < 32 / RPI; ++q) {
-                const long long m = m_base + q * RPI + r_in;
-                rv[q] = *reinterpret_cast<const f32x4*>(rbase + (m < p.M ? m : p.M - 1) * p.ldres);
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int nj = n_wave + j * 32 + l32;
-            const float bv = (p.bias && nj < p.N) ? p.bias[nj] : 0.f;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                float v = acc[i][j][e] + bv;
-                if (p.relu) v = fmaxf(v, 0.f);
-                if (p.relu == 2) v = fminf(v, 6.f);          // ReLU6 (MobileNetV2 blocks)
-                stage[((e & 3) + 8 * (e >> 2) + 4 * hh) * WCOLS + j * 32 + l32] = v;
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < 32 / RPI; ++q) {
-            const int r = q * RPI + r_in;
-            const long long m = m_base + r;
-            f32x4 v = *reinterpret_cast<const f32x4*>(stage + r * WCOLS + c4 * 4);
-            if (m < p.M && n < p.N) {
-                if (vec_ok) {
-                    if (p.res) {
-                        if (RES_AHEAD) v += rv[q];
-                        else v += *reinterpret_cast<const f32x4*>(p.res + m * p.ldres + n);
-                    }
-                    *reinterpret_cast<f32x4*>(p.y + m * p.ldy + n) = v;
-                } else {
-#pragma unroll
-                    for (int t = 0; t < 4; ++t)
-                        if (n + t < p.N) {
-                            float o = v[t];
-                            if (p.res) o += p.res[m * p.ldres + n + t];
-                            p.y[m * p.ldy + n + t] = o;
-                        }
-                }
-            }
-        }
-    }
-}
-
-// pw_epilogue for accumulators of v_mfma_f32_16x16x32_f16: acc[rt][ct] (f32x4) holds rows rt * 16 + 4 * (lane >> 4) + r
-// (r = 0..3), column ct * 16 + (lane & 15) of the wave's (RT * 16) x (CT * 16) sub-tile.  Same LDS transposition, residual
-// prefetch and 16-byte stores as pw_epilogue<..., RES_AHEAD = true>; only the staging map differs.
-// RES_DEPTH: residual pieces (of the 16 per 32-row slab) requested ahead of their use.  16 = the whole slab before its
-// accumulators go through the LDS (kernels with registers to spare); a smaller depth keeps a rolling queue -- the piece of
-// row group q + RES_DEPTH is requested when the piece of row group q has been added -- for kernels at 168 registers per wave.
-template <int WM, int WN, int RT, int CT, int RES_DEPTH = 16>
-__device__ __forceinline__ void pw_epilogue16(const PwArgs& p, f32x4 (&acc)[RT][CT], float* smem, int tile_m, int tile_n, int wave, int lane) {
-    constexpr int BM = WM * RT * 16, BN = WN * CT * 16, WCOLS = CT * 16;
-    constexpr int LPR = WCOLS / 4, RPI = 64 / LPR;
-    const int wm = wave / WN, wn = wave % WN;
-    const int l16 = lane & 15, q4 = lane >> 4;
-    float* const stage = smem + wave * (32 * WCOLS);
-    const bool vec_ok = ((p.N & 3) == 0) && ((p.ldy & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.y) & 15) == 0) &&
-                        (!p.res || (((p.ldres & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.res) & 15) == 0)));
-    const int n_wave = tile_n * BN + wn * WCOLS;
-    const int c4 = lane % LPR, r_in = lane / LPR;
-    const int n = n_wave + c4 * 4;
-    const bool res_vec = vec_ok && p.res != nullptr;
-    float bv[CT];
-#pragma unroll
-    for (int ct = 0; ct < CT; ++ct) {
-        const int nj = n_wave + ct * 16 + l16;
-        bv[ct] = (p.bias && nj < p.N) ? p.bias[nj] : 0.f;
-    }
-#pragma unroll
-    for (int i = 0; i < RT / 2; ++i) {                         // 32-row slabs
-        const long long m_base = (long long)tile_m * BM + (wm * RT + 2 * i) * 16;
-        constexpr int NQ = 32 / RPI;
-        static_assert(RES_DEPTH >= 1 && RES_DEPTH <= NQ, "RES_DEPTH out of range");
-        f32x4 rv[RES_DEPTH];
-        const float* const rbase = res_vec ? p.res + (n < p.N ? n : 0) : nullptr;
-        auto request = [&](int q) {                            // clamped address, no branch around the load
-            const long long m = m_base + q * RPI + r_in;
-            rv[q % RES_DEPTH] = *reinterpret_cast<const f32x4*>(rbase + (m < p.M ? m : p.M - 1) * p.ldres);
-        };
-        constexpr bool kRequestFirst = RES_DEPTH == NQ;        // a short queue is requested behind the staging stores, when
-        if (res_vec && kRequestFirst) {                        // this slab's accumulators no longer occupy registers
-#pragma unroll
-            for (int q = 0; q < RES_DEPTH; ++q) request(q);
-        }
-#pragma unroll
-        for (int h2 = 0; h2 < 2; ++h2)
-#pragma unroll
-            for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float v = acc[2 * i + h2][ct][r] + bv[ct];
-                    if (p.relu) v = fmaxf(v, 0.f);
-                    if (p.relu == 2) v = fminf(v, 6.f);
-                    stage[(h2 * 16 + 4 * q4 + r) * WCOLS + ct * 16 + l16] = v;
-                }
-        if (res_vec && !kRequestFirst) {
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int q = 0; q < RES_DEPTH; ++q) request(q);
-        }
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            const int r = q * RPI + r_in;
-            const long long m = m_base + r;
-            f32x4 v = *reinterpret_cast<const f32x4*>(stage + r * WCOLS + c4 * 4);
-            f32x4 rq = {0.f, 0.f, 0.f, 0.f};
-            if (res_vec) {
-                rq = rv[q % RES_DEPTH];
-                if (q + RES_DEPTH < NQ) request(q + RES_DEPTH);
-            }
-            if (m < p.M && n < p.N) {
-                if (vec_ok) {
-                    if (p.res) v += rq;
-                    *reinterpret_cast<f32x4*>(p.y + m * p.ldy + n) = v;
-                } else {
-#pragma unroll
-                    for (int t = 0; t < 4; ++t)
-                        if (n + t < p.N) {
-                            float o = v[t];
-                            if (p.res) o += p.res[m * p.ldres + n + t];
-                            p.y[m * p.ldy + n + t] = o;
-                        }
-                }
-            }
-        }
-    }
-}
 
 template <int WM, int WN, int TM, int TN, bool CONV>
 __global__ __launch_bounds__(256) void pw_gemm_kernel(PwArgs p) {
@@ -365,7 +181,6 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwArgs p) {
 // XOR-swizzled by (row >> 2) & 3), B_hi/B_lo [4 octets][128][8] halfs from the pre-split packed
 // weights ([K/8][Npad][8] per plane) -- 32 KB, single buffer, 2 barriers per K-tile.
 // =================================================================================================
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ void split_f16x8(const f32x4& a, const f32x4& b, f16x8& hi, f16x8& lo) {
     const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
@@ -377,25 +192,6 @@ __device__ __forceinline__ void split_f16x8(const f32x4& a, const f32x4& b, f16x
         lo[j] = l;
     }
 }
-
-// Phase timing of the K loop (tools/gemm_phase_profile.sh builds with -DASR_GEMM_PHASE_PROFILE; never in the product build):
-// wave 0 of every block accumulates shader-clock deltas per phase and the launcher prints their means.
-#ifdef ASR_GEMM_PHASE_PROFILE
-#define ASR_PHASE_BLOCKS 8192
-__device__ long long g_phase_cycles[ASR_PHASE_BLOCKS * 16];    // per block: 0-7 wave 0's phases, 8-10 loader wave, 11/12 K-loop cycles / 100 MHz ticks
-#define PHASE_MARK(i)                                              \
-    do {                                                           \
-        const long long now_ = (long long)__builtin_readcyclecounter(); \
-        ph[i] += now_ - tprev;                                     \
-        tprev = now_;                                              \
-    } while (0)
-#define PHASE_WAIT_VM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
-#define PHASE_WAIT_LGKM() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
-#else
-#define PHASE_MARK(i)
-#define PHASE_WAIT_VM()
-#define PHASE_WAIT_LGKM()
-#endif
 
 template <int WM, int WN, int TM, int TN, bool CONV>
 __global__ __launch_bounds__(WM * WN * 64) void pw_gemm_f16x3_kernel(PwArgs p) {
@@ -594,51 +390,31 @@ __global__ __launch_bounds__(WM * WN * 64) void pw_gemm_f16x3_kernel(PwArgs p) {
 // separable conv, asr_dwconv3x3_nhwc_split_f16 -- already wrote them as split-f16 chunks, per row and 32-deep K chunk
 // one 128-byte line [hi(32) | lo(32)].  Both operands then reach LDS by LDS-DMA (global_load_lds_dwordx4): no staging
 // registers, no conversion VALU, no ds_write, which is what lets a 256 x 256 tile (half the staged bytes per flop of
-// 128 x 128: the CU takes in only ~20-30 B/clk from L2 under load, DESIGN.md "GEMM phase profile") run with two LDS
-// stages.  8 MFMA waves, each 64 x 128 of the tile; BK = 32.
-//   LDS stage (64 KB): A [256 rows][8 slots of 16 B: hi oct 0-3, lo oct 0-3], slot XOR-swizzled by (row >> 1) & 7 --
-//   applied on the per-lane SOURCE address, the DMA destination is lane-linear --, then B_hi, B_lo [4 oct][256 col][8].
+// 128 x 128: the CU takes in only ~20-30 B/clk from L2 under load) run out of LDS alone.  BK = 32.
+//
+// The workgroup's twelve waves have FIXED ROLES: waves 0-7 only read fragments and issue MFMAs (no vector-memory
+// instruction inside the K loop), each 64 x 128 of the tile; waves 8-11 -- one per SIMD -- only request.
+//
+// LDS = a RING of five 32 KB units (all 160 KB of the CU).  A K-step needs two units: A_k = [256 rows][8 slots of 16 B:
+// hi oct 0-3, lo oct 0-3], slot XOR-swizzled by (row >> 1) & 7 (applied on the per-lane SOURCE address, the DMA
+// destination is lane-linear), and B_k = B_hi, B_lo [4 oct][256 col][8 halfs].  Unit u (A_k = 2k, B_k = 2k + 1) lives in
+// slot u mod 5.  During K-step k the MFMA waves read units 2k and 2k + 1 while the loaders request B_{k+1} (unit 2k + 3)
+// and then A_{k+2} (unit 2k + 4) -- the five live units 2k .. 2k + 4 never share a slot -- and wait with
+// s_waitcnt vmcnt(8): everything but the 8 youngest pieces (A_{k+2}) has landed, i.e. both operands of step k + 1.  A's
+// pieces so have two K-steps to land and B's, requested first, ~1.5.  Round 2's form of this kernel (two 64 KB stages,
+// the whole next stage requested and waited for inside ONE K-step: csrc/diag/gemm_diag.hip) had its loaders' last piece
+// landing at ~2950 of a 3620-cycle K-step whose MFMAs need 3072: every hiccup of the memory system was a stall of all
+// twelve waves at the barrier.
+// Three waves per SIMD leave 168 registers per wave: the MFMA waves hold the 128 accumulators and walk their 64 x 128
+// tile in two 32-row halves (the A fragments of two row tiles at a time, the B fragments double-buffered one column
+// tile ahead; scheduling barriers keep the compiler from hoisting every read, which would spill).  Same MFMA sequence
+// per accumulator as every earlier form => bit-identical results.
 // =================================================================================================
-typedef __attribute__((address_space(3))) void* asr_lds_ptr;
-typedef const __attribute__((address_space(1))) void* asr_gbl_ptr;
-
-__device__ __forceinline__ void glds16(const void* g, void* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((asr_gbl_ptr)g, (asr_lds_ptr)lds_wave_base, 16, 0, 0);
-}
-
-// The workgroup's twelve waves have FIXED ROLES.  Round 1's form of this kernel (8 waves that each requested their own 8
-// pieces of the next stage and then issued their MFMAs; now diagnostic-only, below) left the matrix pipe idle for the ~1000
-// cycles per K-step in which all waves sat in the vector-memory issue queue: a wave pays ~100-150 cycles per 1 KiB LDS-DMA
-// piece whoever issues it, and a wave that is issuing cannot issue MFMAs.  Here waves 0-7 only read fragments and issue
-// MFMAs (no vector-memory instruction inside the K loop); waves 8-11 -- one per SIMD -- only request: 16 pieces each per
-// K-step (~1700 cycles of issue + ~1300 until the last piece has landed, under the ~3100 cycles the SIMD's two MFMA waves
-// need), then meet the MFMA waves at the K-step's barrier.  Three waves per SIMD leave 168 registers per wave: the MFMA
-// waves hold the 128 accumulators and walk their 64 x 128 tile in two 32-row halves (the A fragments of two row tiles at a
-// time, the B fragments double-buffered one column tile ahead; scheduling barriers keep the compiler from hoisting every
-// read, which would spill).  Same MFMA sequence per accumulator as the 8-wave form => bit-identical results; K-step 4100 ->
-// 3600 cycles, 4-6 % less wall time launch for launch (tools/ab_presplit_lw.py: the two forms interleaved in one process;
-// timed in separate processes the chip's clock drift hides the difference), profiles/r02_gemm_loader_wave_experiment.txt.
-// =================================================================================================
-template <typename F, int... I>
-__device__ __forceinline__ void asr_static_for_impl(F& f, std::integer_sequence<int, I...>) {
-    (f(std::integral_constant<int, I>{}), ...);
-}
-template <int N, typename F>
-__device__ __forceinline__ void asr_static_for(F& f) {
-    asr_static_for_impl(f, std::make_integer_sequence<int, N>{});
-}
-
-// MOCK_FUSED (diagnostic library only, tools/ab_presplit_lw.py "experiment"): the four loader waves behave like the producer
-// waves of a fused depthwise -> pointwise layer WOULD -- per K-step each requests 8 B pieces by LDS-DMA, loads its share of
-// the 40 KB of f32 input rows (8 image rows + 2 halo rows of a 32-wide map, 32 channels) into registers two K-steps ahead,
-// issues 416 VALU instructions on them and writes its 8 KB of the A stage with ds_write_b128.  The A stage then holds
-// garbage: TIMING ONLY, an upper bound on what the fusion could reach.
-template <int PIECES_PER_LOADER = 16, bool MOCK_FUSED = false>
-__global__ __launch_bounds__(768, 3) void pw_gemm_f16x3_pre_lw_kernel(PwArgs p) {
+__global__ __launch_bounds__(768, 3) void pw_gemm_f16x3_pre_ring_kernel(PwArgs p) {
     constexpr int BM = 256, BN = 256, WN = 2, RT = 4, CT = 8;
-    constexpr int A_BYTES = BM * 128, B_BYTES = 4 * BN * 16, STAGE_BYTES = A_BYTES + 2 * B_BYTES;
-    constexpr int A_PIECES = A_BYTES / 1024;                   // 32 pieces of 64 lanes x 16 B; then 32 B pieces (hi plane, lo plane)
-    static_assert(4 * PIECES_PER_LOADER * 1024 == STAGE_BYTES, "four loader waves cover one stage");
+    constexpr int UNIT = 32 * 1024, RING = 5, B_PLANE = 4 * BN * 16;      // B unit = hi plane (16 KB) + lo plane
+    constexpr int PIECES = 8;                                  // 1 KiB pieces per loader wave and unit (4 loaders x 8 = 32 KB)
+    static_assert(BM * 128 == UNIT && 2 * B_PLANE == UNIT, "unit size");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     char* const lds = reinterpret_cast<char*>(smem);
 
@@ -649,111 +425,110 @@ __global__ __launch_bounds__(768, 3) void pw_gemm_f16x3_pre_lw_kernel(PwArgs p) 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int KT = p.Kpad / BK;
 
-#ifdef ASR_DIAG_KERNELS
-    if (MOCK_FUSED && wave >= 8) {
-        const int w = wave - 8;
-        const long long plane_bytes = (long long)p.Kpad * p.Npad * 2;
-        const char* bsrc[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int qb = (w * 8 + j) * 64 + lane, plane = qb >> 10, r = qb & 1023, oct = r >> 8, col = r & 255;
-            bsrc[j] = reinterpret_cast<const char*>(p.wp) + plane * plane_bytes + (((long long)oct * p.Npad) + (long long)tile_n * BN + col) * 16;
-        }
-        const char* rsrc[10];
-#pragma unroll
-        for (int r = 0; r < 10; ++r) {
-            long long px = (long long)tile_m * BM - 32 + w * 80 + r * 8 + (lane >> 3);
-            px = px < 0 ? 0 : (px >= p.M ? p.M - 1 : px);
-            rsrc[r] = reinterpret_cast<const char*>(p.x) + (px * p.ldx) * 128 + (lane & 7) * 16;
-        }
-        auto issue_b = [&](int kt, int stage) {
-            char* const st = lds + stage * STAGE_BYTES + A_BYTES + w * 8 * 1024;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) glds16(bsrc[j] + (long long)kt * 4 * p.Npad * 16, st + j * 1024);
-        };
-        f32x4 rows[2][10];
-        auto load_rows = [&](int kt, int buf) {
-#pragma unroll
-            for (int r = 0; r < 10; ++r) rows[buf][r] = *reinterpret_cast<const f32x4*>(rsrc[r] + (long long)(kt < KT ? kt : KT - 1) * 128);
-        };
-        auto produce = [&](int stage, int buf) {                // 416 VALU instructions on the rows, then 8 x ds_write_b128
-#pragma unroll
-            for (int it = 0; it < 13; ++it)
-#pragma unroll
-                for (int r = 0; r < 8; ++r)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(rows[buf][r][e]) : "v"(rows[buf][(r + 1) % 10][e]), "v"(rows[buf][9][(e + 1) & 3]));
-            char* const st = lds + stage * STAGE_BYTES + w * 8 * 1024 + lane * 16;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) *reinterpret_cast<f32x4*>(st + j * 1024) = rows[buf][j];
-        };
-        issue_b(0, 0);
-        load_rows(0, 0);
-        load_rows(1, 1);
-        asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-        produce(0, 0);
-        asm volatile("s_waitcnt vmcnt(10)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        for (int kt = 0; kt < KT; kt += 2) {
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {                       // K-step kt + h: produce the stage of kt + h + 1 from rows[(h + 1) & 1]
-                const int k = kt + h;
-                if (k < KT) {
-                    if (k + 1 < KT) issue_b(k + 1, (k + 1) & 1);
-                    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");       // the rows of k + 1 (requested a K-step ago) are in
-                    if (k + 1 < KT) produce((k + 1) & 1, (h + 1) & 1);
-                    load_rows(k + 2, h & 1);                                 // two K-steps ahead, into the buffer just consumed
-                    asm volatile("s_waitcnt vmcnt(10)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");   // B pieces landed, A stores done
-                    __builtin_amdgcn_s_barrier();
-                }
-            }
-        }
-        return;
-    }
-#endif
     if (wave >= 8) {
-        // ---- loader wave: pieces (wave - 8) * 16 .. + 15 of every stage ------------------------------------------
-        const int first = (wave - 8) * PIECES_PER_LOADER;
-        const char* src[PIECES_PER_LOADER];
-        long long kstep[2];                                     // byte advance per K-step: A pieces, B pieces
-        kstep[0] = 128;
-        kstep[1] = (long long)4 * p.Npad * 16;
+        // ---- loader wave w: pieces 8 w .. 8 w + 7 of every unit ------------------------------------------------------
+        const int first = (wave - 8) * PIECES;
+        const char* src_a[PIECES];
+        const char* src_b[PIECES];
         const long long plane_bytes = (long long)p.Kpad * p.Npad * 2;
+        const long long kstep_b = (long long)4 * p.Npad * 16;     // byte advance per K-step (A: 128)
 #pragma unroll
-        for (int j = 0; j < PIECES_PER_LOADER; ++j) {
+        for (int j = 0; j < PIECES; ++j) {
             const int pi = first + j;
-            if (pi < A_PIECES) {                                // A: (row q >> 3, LDS slot q & 7 holding global slot ^ swizzle)
+            {   // A: (row q >> 3, LDS slot q & 7 holding global slot ^ swizzle)
                 const int q = pi * 64 + lane, row = q >> 3, slot = (q & 7) ^ ((row >> 1) & 7);
                 long long m = (long long)tile_m * BM + row;
                 if (m >= p.M) m = p.M - 1;                      // rows past the end re-read the last row; never stored
-                src[j] = reinterpret_cast<const char*>(p.x) + (m * p.ldx) * 128 + slot * 16;
-            } else {                                            // B: plane (hi, lo), k-octet, column
-                const int qb = (pi - A_PIECES) * 64 + lane, plane = qb >> 10, r = qb & 1023, oct = r >> 8, col = r & 255;
-                src[j] = reinterpret_cast<const char*>(p.wp) + plane * plane_bytes +
-                         (((long long)oct * p.Npad) + (long long)tile_n * BN + col) * 16;
+                src_a[j] = reinterpret_cast<const char*>(p.x) + (m * p.ldx) * 128 + slot * 16;
+            }
+            {   // B: plane (hi, lo), k-octet, column
+                const int qb = pi * 64 + lane, plane = qb >> 10, r = qb & 1023, oct = r >> 8, col = r & 255;
+                src_b[j] = reinterpret_cast<const char*>(p.wp) + plane * plane_bytes +
+                           (((long long)oct * p.Npad) + (long long)tile_n * BN + col) * 16;
             }
         }
-        auto issue = [&](int kt, int stage) {
-            char* const st = lds + stage * STAGE_BYTES + first * 1024;
+        auto issue_a = [&](int kt, int slot) {
+            char* const dst = lds + slot * UNIT + first * 1024;
 #pragma unroll
-            for (int j = 0; j < PIECES_PER_LOADER; ++j)
-                glds16(src[j] + kt * kstep[(first + j) < A_PIECES ? 0 : 1], st + j * 1024);
+            for (int j = 0; j < PIECES; ++j) glds16(src_a[j] + (long long)kt * 128, dst + j * 1024);
         };
-        issue(0, 0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        auto issue_b = [&](int kt, int slot) {
+            char* const dst = lds + slot * UNIT + first * 1024;
+#pragma unroll
+            for (int j = 0; j < PIECES; ++j) glds16(src_b[j] + kt * kstep_b, dst + j * 1024);
+        };
+        issue_a(0, 0);
+        issue_b(0, 1);
+        if (KT > 1) {
+            issue_a(1, 2);
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");    // A_0, B_0 landed; A_1 may still be in flight
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         __builtin_amdgcn_s_barrier();
 #ifdef ASR_GEMM_PHASE_PROFILE
         long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         long long tprev = (long long)__builtin_readcyclecounter();
 #endif
+        int slot_b = 3, slot_a = 4;                              // slots of units 2 kt + 3 and 2 kt + 4
+        // Epilogue operands by LDS-DMA (see the MFMA waves' epilogue below): in the LAST K-step, which requests no more
+        // units, the three slots that hold no live unit take the bias row of the tile (1 KB) and the first row tile of the
+        // residual; row tiles 1 - 3 follow one barrier each behind the K loop, alternating two 64 KB buffers.
+        // A residual row tile = rows wm * 64 + rt * 16 + (0..15) of the four row blocks wm = 0..3 = 64 rows x 1 KB;
+        // row r = wm * 16 + i of it goes to half r >> 5 of its buffer, a piece (one wave instruction) = one row, with the
+        // 16-byte slots XOR-ed by (r & 15) on the SOURCE side (conflict-free ds_read_b128 of 16 rows x one column quad).
+        const bool ep_fast = pw_ep_fast(p);
+        const bool res_dma = ep_fast && p.res != nullptr;
+        auto issue_res = [&](int rt, int slot_h0, int slot_h1) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int r = (wave - 8) * 16 + j;                     // row of the 64-row staging buffer: wm = r >> 4, i = r & 15
+                long long m = (long long)tile_m * BM + (r >> 4) * 64 + rt * 16 + (r & 15);
+                if (m >= p.M) m = p.M - 1;                             // never used
+                int col = tile_n * BN + ((lane ^ (r & 15)) << 2);
+                if (col + 3 >= p.N) col = 0;                           // columns past N: any valid quad, never used
+                glds16(p.res + m * p.ldres + col, lds + ((r >> 5) ? slot_h1 : slot_h0) * UNIT + (r & 31) * 1024);
+            }
+        };
         for (int kt = 0; kt < KT; ++kt) {
-            if (kt + 1 < KT) issue(kt + 1, (kt + 1) & 1);      // the other stage: last read before the previous barrier
-            PHASE_MARK(0);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // landed before anyone is released to read it
+            // both slots were last read in K-step kt - 1, which every MFMA wave left through the previous barrier
+            if (kt + 1 < KT) issue_b(kt + 1, slot_b);
+            if (kt + 2 < KT) {
+                issue_a(kt + 2, slot_a);
+                PHASE_MARK(0);
+                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // all but A_{kt+2}: the operands of step kt + 1 are in
+            } else {
+                if (kt + 1 == KT && ep_fast) {
+                    if (p.bias && wave == 8) {
+                        int col = tile_n * BN + lane * 4;
+                        if (col + 3 >= p.N) col = 0;
+                        glds16(p.bias + col, lds + slot_a * UNIT);
+                    }
+                    if (res_dma) issue_res(0, slot_b - 1 < 0 ? RING - 1 : slot_b - 1, slot_b);
+                }
+                PHASE_MARK(0);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
             PHASE_MARK(1);
             __builtin_amdgcn_s_barrier();
             PHASE_MARK(2);
+            if (kt + 1 < KT) {
+                slot_b = slot_b + 2 >= RING ? slot_b + 2 - RING : slot_b + 2;
+                slot_a = slot_a + 2 >= RING ? slot_a + 2 - RING : slot_a + 2;
+            }
+        }
+        if (res_dma) {
+            // slot_b / slot_a still name the free slots of the last K-step: buffer 0 = (slot_b - 1, slot_b), bias = slot_a,
+            // buffer 1 = the two slots of the last K-step's own units (slot_b + 2, slot_b + 3), read for the last time
+            // before the barrier above
+            const int b0h0 = slot_b - 1 < 0 ? RING - 1 : slot_b - 1, b0h1 = slot_b;
+            const int b1h0 = (slot_b + 2) % RING, b1h1 = (slot_b + 3) % RING;
+#pragma unroll 1
+            for (int rt = 1; rt < 4; ++rt) {
+                if (rt & 1) issue_res(rt, b1h0, b1h1); else issue_res(rt, b0h0, b0h1);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            }
         }
 #ifdef ASR_GEMM_PHASE_PROFILE
         if (tid == 512 && orig < ASR_PHASE_BLOCKS)
@@ -766,9 +541,7 @@ __global__ __launch_bounds__(768, 3) void pw_gemm_f16x3_pre_lw_kernel(PwArgs p) 
     // Waves w and w + 4 share a SIMD: they get the two column halves of the same row block, so that a padded last N-tile
     // (N = 728: 2 of the 8 column tiles of the right half are pure padding, and are skipped) shortens every SIMD's K-step alike.
     const int wm = wave & 3, wn = wave >> 2;
-    const int wave_e = wm * WN + wn;                           // the epilogue's (row block, column half) numbering
     const int ct_valid = min(CT, max(0, (p.N - (tile_n * BN + wn * (CT * 16)) + 15) >> 4));   // column tiles holding real columns
-    const int l16 = lane & 15, oct = lane >> 4;                // A: row = l16, k = 8 oct ..; B: column = l16, same k
     f32x4 acc[RT][CT];
 #pragma unroll
     for (int i = 0; i < RT; ++i)
@@ -781,29 +554,41 @@ __global__ __launch_bounds__(768, 3) void pw_gemm_f16x3_pre_lw_kernel(PwArgs p) 
     long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     long long tprev = (long long)__builtin_readcyclecounter();
 #endif
-    __builtin_amdgcn_s_barrier();                              // stage 0 landed (the loaders waited for it)
+    __builtin_amdgcn_s_barrier();                              // units 0 and 1 landed (the loaders waited for them)
     PHASE_MARK(0);
 #ifdef ASR_GEMM_PHASE_PROFILE
     const long long loop_c0 = (long long)__builtin_readcyclecounter(), loop_r0 = (long long)__builtin_amdgcn_s_memrealtime();
 #endif
+    int slot = 0;                                              // slot of unit 2 kt (A); B sits in the next slot of the ring
     auto kloop = [&](auto CTV_) {
         constexpr int CTV = decltype(CTV_)::value;             // column tiles computed by this wave (even; 8 = all)
         for (int kt = 0; kt < KT; ++kt) {
-            const char* const st = lds + (kt & 1) * STAGE_BYTES;
+            const int off_a = slot * UNIT, off_b = (slot + 1 >= RING ? 0 : slot + 1) * UNIT;    // wave-uniform
+            slot = slot + 2 >= RING ? slot + 2 - RING : slot + 2;
+            // The three lane-dependent byte offsets of the fragment reads (A hi, A lo, B) are RE-DERIVED from the lane id in
+            // every K-step (a dozen VALU instructions against ~3000 cycles of MFMAs): the accumulators and fragments leave
+            // no registers to keep them in, and the compiler would otherwise hoist them out of the loop and spill them --
+            // three scratch reloads with their waits at the head of every K-step.  The empty asm makes the lane id opaque.
+            int ln = lane;
+            asm volatile("" : "+v"(ln));
+            const int l16 = ln & 15, oct = ln >> 4;            // A: row = l16, k = 8 oct ..; B: column = l16, same k
+            // row tile t of this wave starts at row (wm * RT + t) * 16: (row >> 1) & 7 == (l16 >> 1) & 7 for every t
+            const int swz = (l16 >> 1) & 7;
+            const int a_row = off_a + (wm * RT * 16 + l16) * 128;
+            const int a_hi = a_row + ((oct ^ swz) << 4), a_lo = a_row + (((4 + oct) ^ swz) << 4);
+            const int b_col = off_b + (oct * BN + wn * CT * 16 + l16) * 16;
             // 2 halves x CTV column tiles = 2 CTV groups of 6 MFMAs (16 groups for a full tile); the fragments of group g + 1 are requested before the MFMAs of
             // group g (one B double buffer, the A pair of the second half is requested under the last group of the first),
             // and a scheduling barrier per group keeps the compiler from hoisting every read to the top (it would need 160
             // fragment registers and spill).
             f16x8 ah[2], al[2], bh[2], bl[2];
             auto read_a = [&](int half, int i) {                   // hi / lo fragments of row tile 2 * half + i
-                const int row = (wm * RT + 2 * half + i) * 16 + l16, swz = (row >> 1) & 7;
-                ah[i] = *reinterpret_cast<const f16x8*>(st + row * 128 + ((oct ^ swz) << 4));
-                al[i] = *reinterpret_cast<const f16x8*>(st + row * 128 + (((4 + oct) ^ swz) << 4));
+                ah[i] = *reinterpret_cast<const f16x8*>(lds + a_hi + (2 * half + i) * 2048);
+                al[i] = *reinterpret_cast<const f16x8*>(lds + a_lo + (2 * half + i) * 2048);
             };
             auto read_b = [&](int j, int buf) {
-                const int col = (wn * CT + j) * 16 + l16;
-                bh[buf] = *reinterpret_cast<const f16x8*>(st + A_BYTES + (oct * BN + col) * 16);
-                bl[buf] = *reinterpret_cast<const f16x8*>(st + A_BYTES + B_BYTES + (oct * BN + col) * 16);
+                bh[buf] = *reinterpret_cast<const f16x8*>(lds + b_col + j * 256);
+                bl[buf] = *reinterpret_cast<const f16x8*>(lds + b_col + j * 256 + B_PLANE);
             };
             read_a(0, 0);
             read_a(0, 1);
@@ -815,9 +600,13 @@ __global__ __launch_bounds__(768, 3) void pw_gemm_f16x3_pre_lw_kernel(PwArgs p) 
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     f32x4& a4 = acc[2 * half + i][j];
-                    a4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh[g & 1], a4, 0, 0, 0);
-                    a4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl[g & 1], a4, 0, 0, 0);
-                    a4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bh[g & 1], a4, 0, 0, 0);
+                    // the WEIGHTS fragment is the first operand: the MFMA then yields the transposed 16 x 16 tile -- lane
+                    // (l16, q4) holds row l16 and the four CONSECUTIVE columns 4 q4 .. 4 q4 + 3 -- which the epilogue
+                    // stores with one 16-byte store per register quad, no LDS transposition.  Same products (x * w
+                    // commutes), same k order, same accumulation sequence as the untransposed form: bit-identical.
+                    a4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[g & 1], al[i], a4, 0, 0, 0);
+                    a4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[g & 1], ah[i], a4, 0, 0, 0);
+                    a4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[g & 1], ah[i], a4, 0, 0, 0);
                     if (last_of_half0) read_a(1, i);               // the second half's row tile into the registers just consumed
                 }
                 // order inside the group: the next group's fragment reads first, then the MFMAs (the A refills behind their rows)
@@ -829,7 +618,7 @@ __global__ __launch_bounds__(768, 3) void pw_gemm_f16x3_pre_lw_kernel(PwArgs p) 
                 __builtin_amdgcn_sched_barrier(0);
             };
             asr_static_for<2 * CTV>(group);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // this wave's reads of the stage are done
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // this wave's reads of the two units are done
             PHASE_MARK(2);
             __builtin_amdgcn_s_barrier();
             PHASE_MARK(6);
@@ -845,7 +634,16 @@ __global__ __launch_bounds__(768, 3) void pw_gemm_f16x3_pre_lw_kernel(PwArgs p) 
         g_phase_cycles[orig * 16 + 12] = (long long)__builtin_amdgcn_s_memrealtime() - loop_r0;
     }
 #endif
-    pw_epilogue16<4, WN, RT, CT, 4>(p, acc, smem, tile_m, tile_n, wave_e, lane);
+    // ---- epilogue: bias, ReLU, residual, store -- no vector-memory LOAD and no LDS transposition -------------------------
+    // The transposed accumulators go straight out: per register quad one 16-byte store, 64 contiguous bytes per row and
+    // instruction (the next column tile completes the 128-byte line).  What the epilogue has to READ -- the bias row and,
+    // in the last layer of a block, the residual tile -- was put into LDS by the loader waves (above), so the only waits of
+    // these waves are lgkmcnt waits on ds_reads: on gfx9 one vmcnt counter counts loads AND stores in issue order, and a
+    // wave that waits for a residual load also waits for every older store to reach a memory system that all 256 CUs are
+    // writing to at once (the direct-load form of this epilogue measured 1.16x the staged one with a residual,
+    // profiles/r02_gemm_epilogue_experiments.txt #4; without one 0.95x).  `slot` = the first free slot of the last K-step.
+    pw_epilogue16_ring<RT, CT>(p, acc, lds, slot, UNIT, RING, (long long)tile_m * BM + wm * (RT * 16), tile_n * BN + wn * (CT * 16),
+                              wm, wn);
 #ifdef ASR_GEMM_PHASE_PROFILE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     PHASE_MARK(7);
@@ -854,131 +652,6 @@ __global__ __launch_bounds__(768, 3) void pw_gemm_f16x3_pre_lw_kernel(PwArgs p) 
 #endif
 }
 
-#ifdef ASR_DIAG_KERNELS
-// ---- diagnostic build only (csrc/build.py, ASR_BUILD_VARIANT=diag), never part of libasr_hip.so: round 1's form of this
-//      kernel -- 8 waves that each request their own 8 pieces and then issue their MFMAs -- kept so that
-//      tools/ab_presplit_lw.py can A/B the two in one process -------------------------------------------------------------
-template <int WM, int WN, int TM, int TN>
-__global__ __launch_bounds__(WM * WN * 64, 2) void pw_gemm_f16x3_pre_kernel(PwArgs p) {
-    constexpr int NT = WM * WN * 64, BM = WM * TM * 32, BN = WN * TN * 32;
-    constexpr int A_BYTES = BM * 128, B_BYTES = 4 * BN * 16, STAGE_BYTES = A_BYTES + 2 * B_BYTES;
-    constexpr int PA = BM * 8 / NT, PB = 4 * BN / NT;          // 16-byte DMA pieces per thread: A, B (per plane)
-    static_assert((BM * 8) % NT == 0 && (4 * BN) % NT == 0, "tile / thread-count mismatch");
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    char* const lds = reinterpret_cast<char*>(smem);
-
-    const int nwg = gridDim.x, orig = blockIdx.x;
-    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
-    const int lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
-    const int tile_m = lid / p.tiles_n, tile_n = lid % p.tiles_n;
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / WN, wn = wave % WN;
-
-    // per-thread DMA sources: A piece q = tid + NT * i -> (row q >> 3, LDS slot q & 7, holding global slot ^ swizzle)
-    const char* a_src[PA];
-#pragma unroll
-    for (int i = 0; i < PA; ++i) {
-        const int q = tid + NT * i, row = q >> 3, slot = (q & 7) ^ ((row >> 1) & 7);
-        long long m = (long long)tile_m * BM + row;
-        if (m >= p.M) m = p.M - 1;                             // rows past the end re-read the last row; never stored
-        a_src[i] = reinterpret_cast<const char*>(p.x) + (m * p.ldx) * 128 + slot * 16;   // + kt * 128 per K chunk
-    }
-    const long long plane_bytes = (long long)p.Kpad * p.Npad * 2;
-    const char* b_src[PB];
-#pragma unroll
-    for (int i = 0; i < PB; ++i) {
-        const int q = tid + NT * i, oct = q / BN, col = q % BN;
-        b_src[i] = reinterpret_cast<const char*>(p.wp) + (((long long)oct * p.Npad) + (long long)tile_n * BN + col) * 16;  // + kt * 4 * Npad * 16
-    }
-    const long long b_kstep = (long long)4 * p.Npad * 16;
-
-    auto issue_tile = [&](int kt, int stage) {
-        char* const st = lds + stage * STAGE_BYTES;
-#pragma unroll
-        for (int i = 0; i < PA; ++i) glds16(a_src[i] + (long long)kt * 128, st + (wave * 64 + NT * i) * 16);
-#pragma unroll
-        for (int i = 0; i < PB; ++i) {
-            glds16(b_src[i] + kt * b_kstep, st + A_BYTES + (wave * 64 + NT * i) * 16);
-            glds16(b_src[i] + kt * b_kstep + plane_bytes, st + A_BYTES + B_BYTES + (wave * 64 + NT * i) * 16);
-        }
-    };
-
-    // v_mfma_f32_16x16x32_f16: one MFMA spans the whole 32-deep K-step.  Same flops per cycle on paper as the 32x32x16
-    // shape, but under the chip's power management it sustains ~1.18x the rate (profiles/r01_gemm_phase_profile.txt:
-    // 1.55-1.82 vs 1.86-2.20 PFLOP/s in bare loops) and has four independent accumulator chains per column tile.
-    constexpr int RT = 2 * TM, CT = 2 * TN;                    // 16 x 16 tiles of the wave's (RT * 16) x (CT * 16) sub-tile
-    f32x4 acc[RT][CT];
-#pragma unroll
-    for (int i = 0; i < RT; ++i)
-#pragma unroll
-        for (int j = 0; j < CT; ++j)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
-
-    const int KT = p.Kpad / BK;
-#ifdef ASR_GEMM_PHASE_PROFILE
-    long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    long long tprev = (long long)__builtin_readcyclecounter();
-#endif
-    issue_tile(0, 0);
-    __syncthreads();                                           // drains the DMA (vmcnt(0)) and publishes stage 0
-    PHASE_MARK(0);
-#ifdef ASR_GEMM_PHASE_PROFILE
-    const long long loop_c0 = (long long)__builtin_readcyclecounter(), loop_r0 = (long long)__builtin_amdgcn_s_memrealtime();
-#endif
-    const int l16 = lane & 15, oct = lane >> 4;                // A: row = l16, k = 8 oct ..; B: column = l16, same k
-    for (int kt = 0; kt < KT; ++kt) {
-        const char* const st = lds + (kt & 1) * STAGE_BYTES;
-        // All 8 DMA pieces of the next tile go out before the MFMAs (spreading them between the MFMA groups, letting half of
-        // the waves request, or giving the requests to four dedicated loader waves all measured equal in wall clock:
-        // DESIGN.md 4.1, profiles/r02_gemm_loader_wave_experiment.txt).
-        if (kt + 1 < KT) issue_tile(kt + 1, (kt + 1) & 1);     // the other stage: last read before the previous barrier
-        PHASE_MARK(1);
-        f16x8 ah[RT], al[RT];
-#pragma unroll
-        for (int i = 0; i < RT; ++i) {
-            const int row = (wm * RT + i) * 16 + l16, swz = (row >> 1) & 7;
-            ah[i] = *reinterpret_cast<const f16x8*>(st + row * 128 + ((oct ^ swz) << 4));
-            al[i] = *reinterpret_cast<const f16x8*>(st + row * 128 + (((4 + oct) ^ swz) << 4));
-        }
-#pragma unroll
-        for (int j = 0; j < CT; ++j) {
-            const int col = (wn * CT + j) * 16 + l16;
-            const f16x8 bh = *reinterpret_cast<const f16x8*>(st + A_BYTES + (oct * BN + col) * 16);
-            const f16x8 bl = *reinterpret_cast<const f16x8*>(st + A_BYTES + B_BYTES + (oct * BN + col) * 16);
-#pragma unroll
-            for (int i = 0; i < RT; ++i) {
-                f32x4& a4 = acc[i][j];
-                a4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh, a4, 0, 0, 0);
-                a4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl, a4, 0, 0, 0);
-                a4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bh, a4, 0, 0, 0);
-            }
-        }
-        PHASE_MARK(2);
-        PHASE_WAIT_VM();
-        PHASE_MARK(3);
-        __syncthreads();                                       // next stage landed (vmcnt(0)) and everyone is done reading this one
-        PHASE_MARK(6);
-    }
-#ifdef ASR_GEMM_PHASE_PROFILE
-    if (tid == 0 && orig < ASR_PHASE_BLOCKS) {
-        g_phase_cycles[orig * 16 + 11] = (long long)__builtin_readcyclecounter() - loop_c0;
-        g_phase_cycles[orig * 16 + 12] = (long long)__builtin_amdgcn_s_memrealtime() - loop_r0;
-    }
-#endif
-    pw_epilogue16<WM, WN, RT, CT>(p, acc, smem, tile_m, tile_n, wave, lane);
-#ifdef ASR_GEMM_PHASE_PROFILE
-    PHASE_WAIT_VM();
-    PHASE_MARK(7);
-    if (tid == 0 && orig < ASR_PHASE_BLOCKS)
-        for (int i = 0; i < 8; ++i) g_phase_cycles[orig * 16 + i] = ph[i];
-#endif
-}
-
-
-
-
-#endif  // ASR_DIAG_KERNELS
 
 // w [K][N] f32 -> two half planes [Kpad/8][Npad][8] (hi then lo), zero padded
 __global__ __launch_bounds__(256) void pack_weights_f16x3_kernel(const float* __restrict__ w, _Float16* __restrict__ wp, int K,
@@ -1034,8 +707,6 @@ int dispatch(const PwArgs& a, hipStream_t s) {
     if (a.N <= 64) return launch<2, 2, 2, 1, CONV>(a, s);
     return launch<2, 2, 2, 2, CONV>(a, s);
 }
-
-inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 }  // namespace
 
@@ -1213,8 +884,8 @@ extern "C" int asr_pwconv_mfma_f16x3_presplit(const void* x_split, const float* 
     a.tiles_n = (int)asr_cdiv(n, bn);
     const long long nwg = asr_cdiv(m, bm) * a.tiles_n;
     ASR_REQUIRE(nwg <= 0x7fffffffLL, "asr_pwconv_mfma_f16x3_presplit: grid too large");
-    constexpr size_t lds = 2 * (bm * 128 + 2 * 4 * bn * 16);
-    auto kern = pw_gemm_f16x3_pre_lw_kernel<16>;
+    constexpr size_t lds = 5 * 32 * 1024;                      // the five-unit ring: all of the CU's LDS
+    auto kern = pw_gemm_f16x3_pre_ring_kernel;
     static AsrDeviceOnce once;
     ASR_HIP_CHECK(asr_allow_dynamic_lds(once, reinterpret_cast<const void*>(kern), (int)lds));
     hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(768), lds, asr_stream(stream), a);
@@ -1257,49 +928,3 @@ extern "C" int asr_conv3x3_mfma_f16x3(const float* x, const float* w_packed, con
     a.stride = stride; a.pad = pad; a.dil = dil;
     return launch_f16x3(a, cout <= 64 ? 2 : 1, stream);
 }
-
-#ifdef ASR_DIAG_KERNELS
-// timing-only mock of a fused depthwise -> pointwise layer (pw_gemm_f16x3_pre_lw_kernel<16, true>); results are garbage
-extern "C" int asr_diag_pwconv_presplit_exp(const void* x_split, const float* w_packed, const float* bias, const float* residual,
-                                            float* y, int64_t m, int k, int n, int ldx_chunks, int ldy, int ldres, int relu,
-                                            asr_stream_t stream) {
-    ASR_REQUIRE(x_split && w_packed && y && m > 0 && k > 0 && n > 0, "asr_diag_pwconv_presplit_exp: bad arguments");
-    PwArgs a{};
-    a.x = reinterpret_cast<const float*>(x_split); a.wp = w_packed; a.bias = bias; a.res = residual; a.y = y;
-    a.M = m; a.K = k; a.N = n; a.Npad = round_up(n, 128); a.Kpad = round_up(k, BK);
-    a.ldx = ldx_chunks; a.ldy = ldy; a.ldres = ldres; a.relu = relu;
-    a.taps = 1; a.cin = k; a.stride = 1; a.pad = 0; a.dil = 1;
-    ASR_UNSUPPORTED(a.Npad % 256 != 0, "asr_diag_pwconv_presplit_exp: ceil128(n) must be a multiple of 256");
-    a.tiles_n = (int)asr_cdiv(n, 256);
-    const long long nwg = asr_cdiv(m, 256) * a.tiles_n;
-    constexpr size_t lds = 2 * (256 * 128 + 2 * 4 * 256 * 16);
-    auto kern = pw_gemm_f16x3_pre_lw_kernel<16, true>;
-    static AsrDeviceOnce once;
-    ASR_HIP_CHECK(asr_allow_dynamic_lds(once, reinterpret_cast<const void*>(kern), (int)lds));
-    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(768), lds, asr_stream(stream), a);
-    ASR_LAUNCH_CHECK();
-    return ASR_OK;
-}
-
-// asr_pwconv_mfma_f16x3_presplit's arguments on round 1's 8-wave kernel (diagnostic library only; not in include/asr_hip.h)
-extern "C" int asr_diag_pwconv_presplit_8w(const void* x_split, const float* w_packed, const float* bias, const float* residual,
-                                           float* y, int64_t m, int k, int n, int ldx_chunks, int ldy, int ldres, int relu,
-                                           asr_stream_t stream) {
-    ASR_REQUIRE(x_split && w_packed && y && m > 0 && k > 0 && n > 0, "asr_diag_pwconv_presplit_8w: bad arguments");
-    PwArgs a{};
-    a.x = reinterpret_cast<const float*>(x_split); a.wp = w_packed; a.bias = bias; a.res = residual; a.y = y;
-    a.M = m; a.K = k; a.N = n; a.Npad = round_up(n, 128); a.Kpad = round_up(k, BK);
-    a.ldx = ldx_chunks; a.ldy = ldy; a.ldres = ldres; a.relu = relu;
-    a.taps = 1; a.cin = k; a.stride = 1; a.pad = 0; a.dil = 1;
-    ASR_UNSUPPORTED(a.Npad % 256 != 0, "asr_diag_pwconv_presplit_8w: ceil128(n) must be a multiple of 256");
-    a.tiles_n = (int)asr_cdiv(n, 256);
-    const long long nwg = asr_cdiv(m, 256) * a.tiles_n;
-    constexpr size_t lds = 2 * (256 * 128 + 2 * 4 * 256 * 16);
-    auto kern8 = pw_gemm_f16x3_pre_kernel<4, 2, 2, 4>;
-    static AsrDeviceOnce once;
-    ASR_HIP_CHECK(asr_allow_dynamic_lds(once, reinterpret_cast<const void*>(kern8), (int)lds));
-    hipLaunchKernelGGL(kern8, dim3((unsigned)nwg), dim3(512), lds, asr_stream(stream), a);
-    ASR_LAUNCH_CHECK();
-    return ASR_OK;
-}
-#endif

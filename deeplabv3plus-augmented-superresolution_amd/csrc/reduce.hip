@@ -234,21 +234,45 @@ __global__ __launch_bounds__(256) void class_counts_kernel(const int32_t* __rest
 }
 
 // ---- last_activation: softmax / sigmoid over the class axis (model.py:124-125) ----------------------
+__device__ __forceinline__ void activate_row(const float* row, float* o, int classes, int kind) {     // o may be row
+    if (kind == 1) {                       // softmax: exp(x - max) / sum
+        float mx = row[0];
+        for (int c = 1; c < classes; ++c) mx = fmaxf(mx, row[c]);
+        float sum = 0.f;
+        for (int c = 0; c < classes; ++c) sum += expf(row[c] - mx);
+        for (int c = 0; c < classes; ++c) o[c] = expf(row[c] - mx) / sum;
+    } else {                               // sigmoid
+        for (int c = 0; c < classes; ++c) o[c] = 1.0f / (1.0f + expf(-row[c]));
+    }
+}
+
+// Rows of `classes` floats (84 bytes for 21 classes) walked by one thread each are 64-way strided gathers and scatters
+// (measured 0.44 TB/s on the [100,128,128,21] logits of BASELINE configs[2]); like argmax_kernel, a workgroup moves its
+// 256 rows through LDS with coalesced loads and stores and the threads work on the LDS rows, in place.
 __global__ __launch_bounds__(256) void class_activation_kernel(const float* __restrict__ logits, float* __restrict__ out,
                                                               int64_t pixels, int classes, int kind) {
-    for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < pixels; p += (int64_t)gridDim.x * 256) {
-        const float* row = logits + p * classes;
-        float* o = out + p * classes;
-        if (kind == 1) {                       // softmax: exp(x - max) / sum
-            float mx = row[0];
-            for (int c = 1; c < classes; ++c) mx = fmaxf(mx, row[c]);
-            float sum = 0.f;
-            for (int c = 0; c < classes; ++c) sum += expf(row[c] - mx);
-            for (int c = 0; c < classes; ++c) o[c] = expf(row[c] - mx) / sum;
-        } else {                               // sigmoid
-            for (int c = 0; c < classes; ++c) o[c] = 1.0f / (1.0f + expf(-row[c]));
-        }
+    __shared__ float tile[256 * kMaxStageClasses];
+    for (int64_t first = (int64_t)blockIdx.x * 256; first < pixels; first += (int64_t)gridDim.x * 256) {
+        const int64_t rows = min((int64_t)256, pixels - first);
+        const int64_t n = rows * classes;
+        const float* src = logits + first * classes;
+        for (int64_t i = threadIdx.x; i < n; i += 256) tile[i] = src[i];
+        __syncthreads();
+        if ((int64_t)threadIdx.x < rows) {
+            float* row = tile + (int64_t)threadIdx.x * classes;
+            activate_row(row, row, classes, kind);            // every o[c] is written after the last read of row[c'] it needs:
+        }                                                     // softmax re-reads row[c] right before overwriting it
+        __syncthreads();
+        float* dst = out + first * classes;
+        for (int64_t i = threadIdx.x; i < n; i += 256) dst[i] = tile[i];
+        __syncthreads();
     }
+}
+
+__global__ __launch_bounds__(256) void class_activation_direct_kernel(const float* __restrict__ logits, float* __restrict__ out,
+                                                                     int64_t pixels, int classes, int kind) {
+    for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < pixels; p += (int64_t)gridDim.x * 256)
+        activate_row(logits + p * classes, out + p * classes, classes, kind);
 }
 
 int stream_grid(int64_t n) {
@@ -393,8 +417,12 @@ extern "C" int asr_class_activation_f32(const float* logits, float* out, int64_t
                                         asr_stream_t stream) {
     ASR_REQUIRE(logits && out, "asr_class_activation_f32: null pointer");
     ASR_REQUIRE(pixels > 0 && classes > 0 && (kind == 1 || kind == 2), "asr_class_activation_f32: bad arguments (kind 1 = softmax, 2 = sigmoid)");
-    hipLaunchKernelGGL(class_activation_kernel, dim3(stream_grid(pixels)), dim3(256), 0, asr_stream(stream), logits, out, pixels,
-                       classes, kind);
+    if (classes <= kMaxStageClasses)
+        hipLaunchKernelGGL(class_activation_kernel, dim3(stream_grid(pixels)), dim3(256), 0, asr_stream(stream), logits, out, pixels,
+                           classes, kind);
+    else
+        hipLaunchKernelGGL(class_activation_direct_kernel, dim3(stream_grid(pixels)), dim3(256), 0, asr_stream(stream), logits, out,
+                           pixels, classes, kind);
     ASR_LAUNCH_CHECK();
     return ASR_OK;
 }

@@ -326,3 +326,19 @@ def test_mask_pipeline_entry_points(dev):
         a = ops.iou_counts_shared_truth(td, pd, 8, include_bg=bg).cpu().numpy()
         b = ops.iou_counts(td[None].expand(4, -1, -1).contiguous(), pd, 8, include_bg=bg, segments=4).cpu().numpy()
         assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("classes", [21, 5, 40])
+def test_class_activation_matches_torch(dev, classes):
+    """Activation(last_activation) over the class axis (model.py:124-125): LDS-staged rows for <= 32 classes, the direct
+    walk beyond; 1000 pixels = three full tiles of 256 rows and a ragged one."""
+    from asr_amd import ops
+    rng = np.random.default_rng(31)
+    logits = (3.0 * rng.standard_normal((2, 20, 25, classes))).astype(np.float32)
+    ld = ops.to_device(logits)
+    sm = ops.class_activation(ld, "softmax").cpu().numpy()
+    np.testing.assert_allclose(sm, torch.softmax(torch.from_numpy(logits), dim=-1).numpy(), rtol=2e-6, atol=1e-7)
+    np.testing.assert_allclose(sm.sum(-1), 1.0, atol=1e-6)
+    sg = ops.class_activation(ld, "sigmoid").cpu().numpy()
+    np.testing.assert_allclose(sg, torch.sigmoid(torch.from_numpy(logits)).numpy(), rtol=2e-6, atol=1e-7)
+    assert torch.equal(ld, ops.to_device(logits))                         # the input is not touched

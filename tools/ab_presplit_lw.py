@@ -19,13 +19,14 @@ from asr_amd import _lib, ops  # noqa: E402
 
 lib = _lib.load()
 fns = [("8-wave (round 1)", lib.asr_diag_pwconv_presplit_8w)]
-for _sym, _label in (("asr_diag_pwconv_presplit_exp", "MOCK fused (timing only, wrong results)"),):   # csrc/gemm.hip MOCK_FUSED
+for _sym, _label in (("asr_diag_pwconv_presplit_lw", "loader waves, two stages (round 2)"),
+                     ("asr_diag_pwconv_presplit_exp", "MOCK fused (timing only, wrong results)")):   # csrc/diag/gemm_diag.hip
     if hasattr(lib, _sym):
         fns.append((_label, getattr(lib, _sym)))
 for _n, _f in fns:
     _f.restype = C.c_int
     _f.argtypes = _lib.SIGNATURES["asr_pwconv_mfma_f16x3_presplit"][1]
-fns.append(("loader-wave (product)", lib.asr_pwconv_mfma_f16x3_presplit))
+fns.append(("ring (product)", lib.asr_pwconv_mfma_f16x3_presplit))
 NV = len(fns)
 dev = torch.device("cuda")
 torch.manual_seed(0)
@@ -63,7 +64,7 @@ for b, hw, c, n, res in shapes:
             ev[which].append((e0, e1))
     torch.cuda.synchronize()
     t = [np.array([a.elapsed_time(b_) * 1e3 for a, b_ in ev[w]]) for w in range(NV)]
-    same = all(bool(torch.equal(outs[0], outs[w])) for w in range(1, NV))
+    same = all(bool(torch.equal(outs[0], outs[w])) for w in range(1, NV) if "MOCK" not in fns[w][0])
     med = [float(np.median(v)) for v in t]
     print(f"M={m} K={c} N={n} res={int(res)}: " + "   ".join(f"{fns[w][0]} {med[w]:8.1f} us" for w in range(NV)) +
           "   ratios " + " ".join(f"{med[w] / med[0]:.3f}" for w in range(1, NV)) + f"   bit-identical {same}", flush=True)
