@@ -141,7 +141,7 @@ constexpr bool kNtStores = ASR_DW_NT != 0;
 // Maps of up to this many output rows are walked in 16-row strips with 4 rows of input in flight and the activation
 // pattern compiled in; taller ones in 32-row strips with one row in flight (measured per map size).
 #ifndef ASR_DW_SMALL_MAX
-#define ASR_DW_SMALL_MAX 32
+#define ASR_DW_SMALL_MAX 64
 #endif
 template <int R, int S, int SROWS, int PF, bool SPLIT, int ACT>
 __global__ __launch_bounds__(256) void dw_stream_full_kernel(DwArgs p, int tiles_x) {

@@ -95,8 +95,15 @@ __global__ __launch_bounds__(512) void sepconv_fused_kernel(const float* __restr
             in[r] = *reinterpret_cast<const f32x4*>(xin + ((long long)iy * w + ixc) * ldx);
         }
     };
-    if ((long long)blockIdx.x < total) request_rows(blockIdx.x);
-    for (long long tile = blockIdx.x; tile < total; tile += gridDim.x) {
+    // Every workgroup walks ONE contiguous run of tiles (row-major over the image, images one after the other) instead of
+    // every gridDim-th tile: the halo columns of a tile are then re-read by the same workgroup one tile later and its halo
+    // rows one tile row (19 tiles, 1.5 MB of traffic) later -- L2 hits in its own XCD -- where the strided walk had the
+    // neighbours of a tile running at the same time on other XCDs, each fetching the shared lines from HBM for itself
+    // (PMC, round 2: 1.2x the algorithmic bytes).  Same time (the kernel is not bound by its reads), less HBM traffic.
+    const long long per_wg = (total + gridDim.x - 1) / gridDim.x;
+    const long long first = (long long)blockIdx.x * per_wg, last = min(first + per_wg, total);
+    if (first < last) request_rows(first);
+    for (long long tile = first; tile < last; ++tile) {
         const int x0 = (int)(tile % tiles_x) * SF_TW;
         const long long tt = tile / tiles_x;
         const int y0 = (int)(tt % tiles_y) * SF_TH;
@@ -136,11 +143,25 @@ __global__ __launch_bounds__(512) void sepconv_fused_kernel(const float* __restr
                     hi[i] = hf;
                     lo[i] = lf;
                 }
+                // Lanes 16 apart hold neighbouring channel quads (q even / odd) of the same pixel: they trade halves
+                // (v_permlane16_swap: row r of 16 lanes <-> row r ^ 1) so that the even quad's lane holds the 8 hi halfs of
+                // both quads and the odd quad's lane their 8 lo halfs -- ONE 16-byte LDS store per lane into a whole
+                // swizzled slot (conflict-free: 8 consecutive lines per store phase) instead of two 8-byte stores that
+                // hit each bank pair twice (20 % of the LDS cycles were bank conflicts, profiles/r02_pmc_sq.json).  Same
+                // bytes at the same LDS addresses as before.
+                typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+                u32x2 h2 = __builtin_bit_cast(u32x2, hi), l2 = __builtin_bit_cast(u32x2, lo);
+                {   // swap(a = hi, b = lo): a's odd rows <-> b's even rows
+                    const auto sx = __builtin_amdgcn_permlane16_swap(h2.x, l2.x, false, false);
+                    const auto sy = __builtin_amdgcn_permlane16_swap(h2.y, l2.y, false, false);
+                    h2.x = sx[0]; l2.x = sx[1];
+                    h2.y = sy[0]; l2.y = sy[1];
+                }
+                // even quad: {hi(q), hi(q + 1)} -> hi slot q / 2; odd quad: {lo(q - 1), lo(q)} -> lo slot q / 2
+                const u32x4 out = {h2.x, h2.y, l2.x, l2.y};
                 if (lane16 >= 1 && lane16 <= SF_TW) {          // lanes 0 and 15 are the halo columns
                     const int line = (ry0 + r - 2) * SF_TW + lane16 - 1;
-                    char* const base = A + line * LB + (q & 1) * 8;
-                    *reinterpret_cast<f16x4*>(base + sf_swz(q >> 1, line) * 16) = hi;
-                    *reinterpret_cast<f16x4*>(base + sf_swz(OCTS + (q >> 1), line) * 16) = lo;
+                    *reinterpret_cast<u32x4*>(A + line * LB + sf_swz(((q & 1) ? OCTS : 0) + (q >> 1), line) * 16) = out;
                 }
             }
 #pragma unroll
@@ -149,7 +170,7 @@ __global__ __launch_bounds__(512) void sepconv_fused_kernel(const float* __restr
                 win[1][k] = win[2][k];
             }
         }
-        request_rows(min(tile + (long long)gridDim.x, total - 1));    // next tile's rows (the last tile re-requests its own)
+        request_rows(min(tile + 1, last - 1));                // next tile's rows (the last tile re-requests its own)
         __syncthreads();
         // ---- stage 2: out[line][n] = sum_c A[line][c] * W[c][n] on split-f16 MFMA, A from the LDS image ----
         f32x16 acc2[2];

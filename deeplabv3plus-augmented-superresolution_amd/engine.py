@@ -293,7 +293,7 @@ class DeeplabEngine:
             b, h, w, c = x.shape
             ho, wo = (h, w) if stride == 1 else ((h + 2 * rate - (2 * rate + 1)) // stride + 1,
                                                  (w + 2 * rate - (2 * rate + 1)) // stride + 1)
-            srows = 16 if ho <= 32 else 32
+            srows = 16 if ho <= 64 else 32           # csrc/dwconv.hip: ASR_DW_SMALL_MAX
             split_ok = (pp.get("fn", "").endswith("f16x3") and (-(-pp["n"] // 128) * 128) % 256 == 0 and not pw_kw.get("out_off")
                         and pw_kw.get("sub", 1) == 1 and ((stride == 1 and rate in (1, 2)) or (stride == 2 and rate == 1))
                         and ho % srows == 0 and c % 8 == 0 and b <= 65535 and b * ho * wo >= 256 and "presplit" not in self.disabled)
