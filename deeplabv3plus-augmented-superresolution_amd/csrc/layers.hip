@@ -218,7 +218,12 @@ __global__ __launch_bounds__(256) void conv3x3_stem_mfma_kernel(const float* __r
 // The 32-channel intermediate (839 MB per 100 copies, written once and re-read nine times through L2 by the implicit
 // GEMM of the two-kernel form) never leaves the CU.
 constexpr int ES_T = 16, ES_H = ES_T + 2, ES_NPIX = ES_H * ES_H, ES_GROUPS = (ES_NPIX + 31) / 32;
-constexpr int ES_T1_BYTES = ES_NPIX * 128, ES_B_BYTES = 36 * 64 * 16, ES_LDS_BYTES = ES_T1_BYTES + 2 * ES_B_BYTES;   // 112.5 KB
+// Row stride of the LDS image in lines.  Stage 2 reads, per ds_read_b128 phase of 16 lanes, 8 lines of one tile row and 8 of
+// the next; with the natural stride 18 two of the 16 land on the same bank group as two others (28 % of the LDS cycles
+// were bank conflicts, profiles/r02_pmc_sq.json); a stride that is a multiple of 16 keeps the XOR swizzle's 16 residues
+// distinct across the two rows.
+constexpr int ES_LS = 32;
+constexpr int ES_T1_BYTES = ES_H * ES_LS * 128, ES_B_BYTES = 36 * 64 * 16, ES_LDS_BYTES = ES_T1_BYTES + 2 * ES_B_BYTES;   // 144 KB
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 __global__ __launch_bounds__(512) void entry_stem_fused_kernel(const float* __restrict__ x, const float* __restrict__ w1,
@@ -269,7 +274,7 @@ __global__ __launch_bounds__(512) void entry_stem_fused_kernel(const float* __re
     // LDS image -- measured no faster: 982 vs 938 us; the tile time is set by stage 2's MFMAs and the 64 KB of stores.)
     struct Gathered {
         float a[16];
-        int t;
+        int t, line;                                           // pixel of the 18 x 18 halo tile, its line in the LDS image
         bool in_map;
     };
     auto gather = [&](long long tile, int g) -> Gathered {
@@ -280,6 +285,7 @@ __global__ __launch_bounds__(512) void entry_stem_fused_kernel(const float* __re
         const float* xin = x + (tt / tiles_y) * h_in * w_in * ldx;
         r.t = 32 * g + l32;
         const int tyy = r.t / ES_H, txx = r.t - tyy * ES_H;
+        r.line = tyy * ES_LS + txx;
         const int oy1 = ty0 - 1 + tyy, ox1 = tx0 - 1 + txx;
         r.in_map = r.t < ES_NPIX && oy1 >= 0 && oy1 < h1 && ox1 >= 0 && ox1 < w1d;
         const int iy0 = 2 * oy1, ix0 = 2 * ox1;                // 'same' at stride 2 on an even input: pad bottom / right only
@@ -312,8 +318,8 @@ __global__ __launch_bounds__(512) void entry_stem_fused_kernel(const float* __re
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[s], xh[s], acc, 0, 0, 0);
         }
         if (r.t < ES_NPIX) {
-            char* const line = T1 + r.t * 128;
-            const int swz = (r.t >> 1) & 7;
+            char* const line = T1 + r.line * 128;
+            const int swz = (r.line >> 1) & 7;
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {                   // registers 4 g4 .. 4 g4 + 3 = channels 8 g4 + 4 hh + 0..3
                 f16x4 hi, lo;
@@ -352,7 +358,7 @@ __global__ __launch_bounds__(512) void entry_stem_fused_kernel(const float* __re
 #pragma unroll 3                                               // fully unrolled, the hoisted LDS reads spill
         for (int tap = 0; tap < 9; ++tap) {
             const int ky = (tap * 11) >> 5;                    // tap / 3 for tap < 9
-            const int tp = (yy + ky) * ES_H + xx + (tap - 3 * ky);
+            const int tp = (yy + ky) * ES_LS + xx + (tap - 3 * ky);
             const char* const line = T1 + tp * 128;
             const int swz = (tp >> 1) & 7;
 #pragma unroll

@@ -391,7 +391,7 @@ class DeeplabEngine:
                 label="gap", out=pooled)
             pp = pw(pooled, "image_pooling", relu=True)
             add("asr_resize_bilinear_f32", (pp.ptr, cat.ptr, b, 1, 1, 256, fh, fw, pp.ld, cat.ld), "misc", 0,
-                4.0 * b * fh * fw * 256)
+                4.0 * b * fh * fw * 256, out=cat)
             release(pooled)
             release(pp)
             pw(x, "aspp0", out=cat, out_off=256, relu=True)
@@ -444,7 +444,7 @@ class DeeplabEngine:
             label="gap", out=pooled)
         pp = pw(pooled, "image_pooling", relu=True)
         add("asr_resize_bilinear_f32", (pp.ptr, cat.ptr, b, 1, 1, 256, fh, fw, pp.ld, cat.ld), "misc", 0,
-            4.0 * b * fh * fw * 256)
+            4.0 * b * fh * fw * 256, out=cat)
         release(pooled)
         release(pp)
         pw(x, "aspp0", out=cat, out_off=256, relu=True)
@@ -499,7 +499,7 @@ class DeeplabEngine:
             sh, sw = self.first_upsample_size          # Resizing(*first_upsample_size) (model.py:271-272, 285-286)
             cat2 = new((b, sh, sw, fch))
         add("asr_resize_bilinear_f32", (feat.ptr, cat2.ptr, b, fh, fw, fch, sh, sw, feat.ld, cat2.ld), "misc", 0,
-            4.0 * b * sh * sw * fch)
+            4.0 * b * sh * sw * fch, out=cat2)
         release(feat)
         if skip is not None:
             pw(skip, "feature_projection0", out=cat2, out_off=256, relu=True)
@@ -566,7 +566,18 @@ class DeeplabEngine:
             moved_all.update(moved)
         return moved_all
 
-    def _calibrate_pass(self, x_dev, verbose):
+    def range_report(self, x_dev):
+        """On-demand check of the split-f16 range guard for a GIVEN input batch x_dev [B,H,W,3] (nothing is re-routed, the
+        hot path is untouched): runs it through the opened-up plan and returns {layer: max |A operand|} of every layer still
+        on a split-f16 kernel whose operand on THIS input is within SPLIT_HEADROOM of 2^15 or entirely below 2^-10 -- i.e.
+        the layers that calibrate_range would move.  An empty dict means the routing decided on the probe batch also holds
+        for this input; otherwise call calibrate_range(x_dev) (the kernels saturate at +-65504: an out-of-range input
+        gives finite, inexact logits, never inf / NaN, and never a signal by itself)."""
+        if self.precision != "f16x3":
+            return {}
+        return {k: v for k, v in self._calibrate_pass(x_dev, verbose=False, dry_run=True).items()}
+
+    def _calibrate_pass(self, x_dev, verbose, dry_run=False):
         B, H, Wd, _ = x_dev.shape
         saved = self.disabled
         self.disabled = saved | {"fused_stem", "fused_sepconv"}      # their internal operands become visible tensors
@@ -584,13 +595,13 @@ class DeeplabEngine:
             if name in self.SPLIT_GEMMS and layer in self.p and layer not in self.routed_f32:
                 m = maxima.get(args[0])
                 if m is not None and (m != m or (m > 0.0 and (m * SPLIT_HEADROOM >= SPLIT_MAX or m < SPLIT_ACT_MIN))):
-                    moved[layer] = (f"max |activation| = {m:.3g} on the probe batch, outside "
-                                    f"[{SPLIT_ACT_MIN:.3g}, {SPLIT_MAX / SPLIT_HEADROOM:.3g})")
+                    moved[layer] = m if dry_run else (f"max |activation| = {m:.3g} on the probe batch, outside "
+                                                      f"[{SPLIT_ACT_MIN:.3g}, {SPLIT_MAX / SPLIT_HEADROOM:.3g})")
             _lib.check(getattr(lib, name)(*args, s), name)
             for buf in (out if isinstance(out, (list, tuple)) else ([out] if out is not None else [])):
                 t = buf.t.view(torch.float16) if name in self.SPLIT_PRODUCERS else buf.t
                 maxima[buf.ptr] = float(t.abs().max())               # (a saturated split half reads 65504: still caught)
-        if moved:
+        if moved and not dry_run:
             self.routed_f32.update(moved)
             self._w = self._host_weights
             for layer in moved:
@@ -617,7 +628,9 @@ class DeeplabEngine:
         assert c == 3
         plan = self.plan(B, H, Wd, lane)
         xin = plan["x_in"].t
-        if x_dev.data_ptr() != xin.data_ptr():          # (input_view: already in place)
+        in_place = (x_dev.data_ptr() == xin.data_ptr() and x_dev.is_contiguous() and x_dev.numel() == xin.numel()
+                    and x_dev.dtype == xin.dtype)
+        if not in_place:                                 # (input_view: already in place)
             xin.copy_(x_dev.reshape(-1))
         lib = _lib.load()
         s = _lib.stream_ptr()

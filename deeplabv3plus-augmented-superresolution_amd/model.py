@@ -63,16 +63,25 @@ class DeeplabV3Plus:
         # Seeded initialisation of the whole inventory: what Keras holds before load_weights (random init there).
         params = W.make_synthetic_weights(self.synthetic_seed, self.classes, backbone=self.backbone, alpha=self.alpha,
                                           decoder=decoder, class_prediction=final_class_prediction)
-        path = self.weights_path or os.environ.get("ASR_WEIGHTS")
+        path = self.weights_path          # an explicit argument only: no environment variable changes which weights a model has
+        loaded_ok = False
         if self.load_weights and path:
             # local file only (never the URL of model.py:9); by_name=True, skip_mismatch=True like model.py:145
-            params, skipped = W.merge_by_name(params, W.load_weights(path))
+            template = params
+            params, skipped = W.merge_by_name(template, W.load_weights(path))
             for name, why in skipped:
                 print(f"asr_amd: layer variable {name} not loaded from {path} ({why}); keeping its seeded initialisation",
                       file=sys.stderr)
+            frac = W.loaded_fraction(template, skipped)
+            loaded_ok = frac > 0.0
+            if frac < 0.5:      # e.g. an Xception checkpoint given to a MobileNet model: (nearly) nothing matched by name
+                warnings.warn(f"DeeplabV3Plus: only {100.0 * frac:.0f} % of the model's kernels were found in {path} "
+                              f"(backbone={self.backbone!r}, classes={self.classes}); the rest keeps its SEEDED SYNTHETIC "
+                              "initialisation -- masks and IoUs are meaningless as segmentation results.", RuntimeWarning,
+                              stacklevel=2)
         elif self.load_weights:
             # The reference would download the pretrained .h5 here (model.py:134-143): unavailable offline.
-            warnings.warn("DeeplabV3Plus(load_weights=True) without weights_path / $ASR_WEIGHTS: the pretrained checkpoint is a "
+            warnings.warn("DeeplabV3Plus(load_weights=True) without weights_path: the pretrained checkpoint is a "
                           "network download in the reference and is NOT available here -- running on SEEDED SYNTHETIC "
                           "weights; masks and IoUs are meaningless as segmentation results (pass load_weights=False to "
                           "say so explicitly).", RuntimeWarning, stacklevel=2)
@@ -80,7 +89,7 @@ class DeeplabV3Plus:
                             precision=self.precision, backbone=self.backbone, alpha=self.alpha, OS=self.OS,
                             reshape_outputs=self.reshape_outputs, decoder=decoder, first_upsample_size=first_upsample_size,
                             class_prediction=final_class_prediction,
-                            calibrate=bool(self.load_weights and path))   # real weights: activation ranges are unknown
+                            calibrate=loaded_ok)           # weights from a file: their activation ranges are unknown
 
 
 class DeeplabModel:
@@ -158,6 +167,13 @@ class DeeplabModel:
         if not isinstance(x, torch.Tensor):
             x = torch.as_tensor(np.ascontiguousarray(x, dtype=np.float32))
         return self.engine.calibrate_range(x.to(self.device).contiguous())
+
+    def check_range(self, x):
+        """{layer: max |operand|} of the split-f16 layers that THIS input x [B,H,W,3] drives out of the f16 split's range
+        (DeeplabEngine.range_report; empty = fine).  On demand: costs one opened-up forward pass of x, nothing per predict."""
+        if not isinstance(x, torch.Tensor):
+            x = torch.as_tensor(np.ascontiguousarray(x, dtype=np.float32))
+        return self.engine.range_report(x.to(self.device).contiguous())
 
     def _upsample(self, logits, hw):
         """Resizing(H, W, bilinear) of the logits (model.py:108-111); channels padded to a multiple

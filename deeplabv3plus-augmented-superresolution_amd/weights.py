@@ -241,22 +241,37 @@ def load_weights(path):
 
 
 def merge_by_name(template, loaded):
-    """Keras ``load_weights(by_name=True, skip_mismatch=True)`` (model.py:145) on ``{layer}/{variable}`` dictionaries:
-    every variable of ``template`` (the model's own inventory, already initialised) takes the loaded array of the same
-    name when its shape matches; a missing or mismatched variable keeps its initial value and is reported.  Loaded
-    entries the model has no layer for are ignored, as Keras does.  Returns (params, [(name, reason)])."""
+    """Keras ``load_weights(by_name=True, skip_mismatch=True)`` (model.py:145) on ``{layer}/{variable}`` dictionaries.
+    Matching is PER LAYER, like Keras: a layer takes its weights from the file only when the file holds every variable of
+    it with the right shape; a layer with a missing or mismatched variable keeps ALL its initial values (Keras skips the
+    whole layer with a warning) and each of its variables is reported.  Loaded entries the model has no layer for are
+    ignored, as Keras does.  Returns (params, [(variable name, reason)])."""
+    by_layer = {}
+    for name in template:
+        by_layer.setdefault(name.rsplit("/", 1)[0], []).append(name)
     out, skipped = {}, []
-    for name, init in template.items():
-        got = loaded.get(name)
-        if got is None:
-            out[name] = init
-            skipped.append((name, "absent from the file"))
-        elif tuple(np.shape(got)) != tuple(init.shape):
-            out[name] = init
-            skipped.append((name, f"shape {tuple(np.shape(got))} != {tuple(init.shape)}"))
-        else:
-            out[name] = np.asarray(got, dtype=np.float32)
+    for layer, names in by_layer.items():
+        problems = {}
+        for name in names:
+            got = loaded.get(name)
+            if got is None:
+                problems[name] = "absent from the file"
+            elif tuple(np.shape(got)) != tuple(template[name].shape):
+                problems[name] = f"shape {tuple(np.shape(got))} != {tuple(template[name].shape)}"
+        for name in names:
+            if problems:
+                out[name] = template[name]
+                skipped.append((name, problems.get(name, f"layer {layer} skipped as a whole ({next(iter(problems.values()))})")))
+            else:
+                out[name] = np.asarray(loaded[name], dtype=np.float32)
     return out, skipped
+
+
+def loaded_fraction(template, skipped):
+    """Fraction of the model's convolution / depthwise kernels that came from the file (0 = the file matched nothing)."""
+    kernels = [n for n in template if n.endswith("/kernel") or n.endswith("/depthwise_kernel")]
+    missed = {n for n, _ in skipped}
+    return (sum(1 for n in kernels if n not in missed) / len(kernels)) if kernels else 0.0
 
 
 def bn_scale_shift(weights, name, eps):

@@ -241,7 +241,12 @@ def test_range_guard_routes_layers_to_the_exact_f32_kernels(dev, synthetic, case
         assert "aspp0" in model.engine.routed_f32
     raw = model.predict(x, batch_size=2)
     assert np.isfinite(raw).all()
+    # the on-demand check names the layers this input drives out of range without changing anything ...
+    report = model.check_range(x)
+    routed_before = dict(model.engine.routed_f32)
+    assert (len(report) > 0) == (case != "large-weights") and model.engine.routed_f32 == routed_before
     moved = model.calibrate_range(x)
+    assert set(report) <= set(moved)                          # ... and calibration then moves (at least) those
     if case == "large-activations":
         assert len(moved) >= 10 and "middle_flow_unit_8_separable_conv2_pointwise" in moved
     elif case == "tiny-activations":     # the next BatchNorm's beta brings the scale back: only the stem's second conv sees it
@@ -249,3 +254,6 @@ def test_range_guard_routes_layers_to_the_exact_f32_kernels(dev, synthetic, case
     got = model.predict(x, batch_size=2)
     np.testing.assert_allclose(got, ref, rtol=0, atol=2e-4 * np.abs(ref).max())
     assert model.calibrate_range(x) == {}                       # idempotent: nothing left to move
+    assert model.check_range(x) == {}                           # and the input is now inside every layer's range
+    if case == "large-activations":                             # a LATER input beyond the probe's range is reported on demand
+        assert len(model.check_range(x * np.float32(40.0))) > 0

@@ -231,7 +231,15 @@ def test_weights_merge_by_name_skips_mismatches():
     names = dict(skipped)
     assert set(merged) == set(tmpl)
     assert "absent" in names["aspp0_BN/gamma"] and np.array_equal(merged["aspp0_BN/gamma"], tmpl["aspp0_BN/gamma"])
-    assert set(names) == {"aspp0_BN/gamma", "custom_logits_semantic/kernel", "custom_logits_semantic/bias"}
+    # per LAYER, like Keras: aspp0_BN lost one variable -> all four of its variables keep their initial values
+    bn = {"aspp0_BN/gamma", "aspp0_BN/beta", "aspp0_BN/moving_mean", "aspp0_BN/moving_variance"}
+    assert set(names) == bn | {"custom_logits_semantic/kernel", "custom_logits_semantic/bias"}
+    assert all(np.array_equal(merged[k], tmpl[k]) for k in bn) and "as a whole" in names["aspp0_BN/beta"]
     assert np.array_equal(merged["entry_flow_conv1_1/kernel"], ckpt["entry_flow_conv1_1/kernel"])
+    assert W.loaded_fraction(tmpl, skipped) > 0.98
     same, none = W.merge_by_name(ckpt, dict(ckpt))
     assert none == [] and all(np.array_equal(same[k], ckpt[k]) for k in ckpt if k != "not_a_layer/kernel")
+    # a checkpoint of another backbone matches (almost) nothing by name
+    mob = W.make_synthetic_weights(7, 21, backbone="mobilenet")
+    _m, sk = W.merge_by_name(mob, ckpt)
+    assert W.loaded_fraction(mob, sk) < 0.2
