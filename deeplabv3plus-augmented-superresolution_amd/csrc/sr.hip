@@ -44,12 +44,14 @@ __global__ __launch_bounds__(256) void sr_init_kernel(const float* __restrict__ 
 
 // ---- zero-bordered planes ---------------------------------------------------------------------------
 // The solver keeps the images its bilinear gathers sample (the current x for K_fwd, the per-copy gradient planes G_R for
-// the backward gather) with a zero border: row stride W + 8 (4 zero columns each side), 2 zero rows above and below.  A
+// the backward gather) with a zero border: row stride W + 64 (32 zero columns each side), 2 zero rows above and below.  A
 // 2 x 2 tap block whose floor coordinate is clamped to [-2, W] x [-2, H] then reads zeros exactly where the unclamped
 // taps fall outside the image (TF's CONSTANT-0 fill), so a sample is two unaligned 8-byte loads with no per-tap bounds
 // test and no select; the weights still come from the unclamped coordinate.  Same products and sums as
 // asr_tf_bilinear over a bounds-checked reader -> bit-identical.
-constexpr int kGrPadX = 4, kGrPadY = 2;
+// 32 border columns = one 128-byte line: every row's payload then starts on a line (with 4 columns -- enough for the taps --
+// each 256-byte row segment a wave writes straddled three lines: K_gt + K_bwd 68 -> 62 us per iteration at N = 100).
+constexpr int kGrPadX = 32, kGrPadY = 2;
 __host__ __device__ inline size_t sr_gr_plane_elems(int H, int W) { return (size_t)(H + 2 * kGrPadY) * (size_t)(W + 2 * kGrPadX); }
 typedef float asr_f2u __attribute__((ext_vector_type(2), aligned(4)));
 
@@ -75,7 +77,7 @@ __device__ __forceinline__ void sr_map_affine(const AsrTf8& t, float x, float y,
 }
 
 // ---- K_fwd --------------------------------------------------------------------------------
-// One thread per LR residual element (b, n, i, j).  BORDERED: x is the solver's zero-bordered copy [batch, H+4, W+8].
+// One thread per LR residual element (b, n, i, j).  BORDERED: x is the solver's zero-bordered copy [batch, H+4, W+64].
 template <bool BORDERED>
 __global__ __launch_bounds__(256) void sr_forward_residual_kernel(
     const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ rot_tf,
@@ -329,10 +331,10 @@ constexpr int kBwdSplit = 4, kBwdPixX = 32, kBwdPixY = 2, kBwdPix = kBwdPixX * k
 // at the integer HR position c of copy n, i.e. the registered gradient of the translate applied to G_T -- depends on
 // (n, c) only, yet the fused kernel re-derives it for each of the 4 rotation taps of every (pixel, copy) pair (16 nested
 // taps, ~250 VALU instructions per pair; the kernel is VALU-bound).  sr_grad_translate_kernel evaluates it ONCE per
-// (n, c) into a zero-bordered [batch*n, H + 4, W + 8] plane (written and re-read through L2 / the Infinity Cache: 107 MB
+// (n, c) into a zero-bordered [batch*n, H + 4, W + 64] plane (written and re-read through L2 / the Infinity Cache: 119 MB
 // at N = 100, 512^2) and sr_backward_gather_kernel takes the rotation's 4 taps from that plane.  Same products and sums
 // on the same operands as the fused kernel (x blend, then y blend, then the rotation's bilinear weights) -> bit-identical.
-//   Plane geometry: row stride W + 8 (4 zero columns each side), 2 zero rows above and below.  A tap pair whose floor
+//   Plane geometry: row stride W + 64 (32 zero columns each side), 2 zero rows above and below.  A tap pair whose floor
 //   coordinate is clamped to [-2, W] x [-2, H] reads only zeros wherever the unclamped taps are out of the image, so the
 //   gather needs no per-tap bounds test and no select.
 constexpr int kGrRows = 16;   // HR rows per wave of sr_grad_translate_kernel
@@ -788,7 +790,7 @@ int sr_plane_chunk(int batch, int n, int H, int W, int requested) {
 }
 size_t sr_workspace_bytes(int batch, int n, int H, int W, int h, int w, int chunk) {
     // residuals [batch*n, h, w] + the ping-pong x [batch, H, W] + the running data-term sum [batch, H, W] + the
-    // zero-bordered planes [H + 4, W + 8]: G_R per copy of a chunk, x per image
+    // zero-bordered planes [H + 4, W + 64]: G_R per copy of a chunk, x per image
     return sizeof(float) * ((size_t)batch * n * h * w + 2 * (size_t)batch * H * W +
                             ((size_t)batch * chunk + batch) * sr_gr_plane_elems(H, W));
 }
