@@ -1,6 +1,10 @@
 // Micro-benchmark: how fast can a CU get a 256 KB output tile out of its registers?  G workgroups (one per CU) of 8 waves;
-// every wave issues 32 global_store_dwordx4 (1 KB per instruction) -- either 16 rows x 64 B (the transposed-MFMA epilogue's
-// pattern, row stride 2912 B) or 2 rows x 512 B (the LDS-transposed epilogue's pattern) -- then waits for them.  Prints the
+// every wave issues 32 global_store_dwordx4 (1 KB per instruction) -- 16 rows x 64 B (the transposed-MFMA epilogue's
+// pattern), 8 rows x 128 B (whole lines: two column tiles per store) or 2 rows x 512 B (the LDS-transposed epilogue's
+// pattern), at a row stride of 728 floats (2912 B, not a multiple of the 128-byte line) and of 736 (what the engine
+// allocates) -- then waits for them.  Round 3, G = 256: 13.6 K cycles at stride 728 against 8.7 K at 736 for the 64 B and
+// the 128 B segments alike (30 B/clk per CU), 21.4 K / 12.4 K for the 512 B rows: the alignment of the rows matters, the
+// segment length does not.  Prints the
 // mean cycles per workgroup until issued and until drained, for G = 8 .. 256: a per-CU limit shows at every G, a shared
 // (fabric / HBM) limit only at large G.
 //   hipcc --offload-arch=gfx950 -O3 tools/ubench_store_burst.hip -o ubs && ./ubs
@@ -27,6 +31,13 @@ __global__ __launch_bounds__(512) void k(float* __restrict__ y, long long* __res
 #pragma unroll
                 for (int rt = 0; rt < 4; ++rt)
                     *reinterpret_cast<f32x4*>(tile + (long long)(wm * 64 + rt * 16 + l16) * ldy + wn * 128 + ct * 16 + q4 * 4) = v;
+        } else if (PATTERN == 2) {                              // 8 rows x 128 B per instruction (two column tiles per store)
+            const int l8 = lane & 7, q8 = lane >> 3;
+#pragma unroll
+            for (int ct = 0; ct < 8; ct += 2)
+#pragma unroll
+                for (int rt = 0; rt < 8; ++rt)
+                    *reinterpret_cast<f32x4*>(tile + (long long)(wm * 64 + rt * 8 + l8) * ldy + wn * 128 + ct * 16 + q8 * 4) = v;
         } else {                                                // 2 rows x 512 B per instruction
             const int c4 = lane & 31, r_in = lane >> 5;
 #pragma unroll
@@ -43,14 +54,17 @@ __global__ __launch_bounds__(512) void k(float* __restrict__ y, long long* __res
 }
 
 int main() {
-    const int ldy = 728, rounds = 8;
+    const int rounds = 8;
     float* y; long long* cyc;
-    hipMalloc(&y, (size_t)256 * rounds * 256 * ldy * 4 + 4096);
+    hipMalloc(&y, (size_t)256 * rounds * 256 * 736 * 4 + 4096);
     hipMalloc(&cyc, sizeof(long long) * 512);
-    for (int pattern = 0; pattern < 2; ++pattern)
-        for (int g : {8, 32, 64, 128, 256}) {
+    for (int ldy : {728, 736}) {
+    printf("row stride %d floats\n", ldy);
+    for (int pattern = 0; pattern < 3; ++pattern)
+        for (int g : {8, 64, 256}) {
             for (int rep = 0; rep < 2; ++rep) {
                 if (pattern == 0) hipLaunchKernelGGL(k<0>, dim3(g), dim3(512), 0, 0, y, cyc, ldy, rounds);
+                else if (pattern == 2) hipLaunchKernelGGL(k<2>, dim3(g), dim3(512), 0, 0, y, cyc, ldy, rounds);
                 else hipLaunchKernelGGL(k<1>, dim3(g), dim3(512), 0, 0, y, cyc, ldy, rounds);
                 hipDeviceSynchronize();
             }
@@ -59,7 +73,8 @@ int main() {
             double a = 0, b = 0;
             for (int i = 0; i < g; ++i) { a += h[2 * i]; b += h[2 * i + 1]; }
             printf("%s  G=%3d workgroups: issued after %6.0f cycles, drained after %6.0f cycles  (%.1f B/clk per CU)\n",
-                   pattern == 0 ? "16 rows x 64 B " : "2 rows x 512 B ", g, a / g, b / g, 262144.0 / (b / g));
+                   pattern == 0 ? "16 rows x 64 B " : (pattern == 2 ? "8 rows x 128 B " : "2 rows x 512 B "), g, a / g, b / g, 262144.0 / (b / g));
         }
+    }
     return 0;
 }
