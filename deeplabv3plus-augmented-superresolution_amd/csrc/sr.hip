@@ -59,10 +59,15 @@ typedef float asr_f2u __attribute__((ext_vector_type(2), aligned(4)));
 // non-negative, so the loads take the scalar plane base + a 32-bit lane offset.
 __device__ __forceinline__ float sr_bilinear_bordered(const float* __restrict__ plane, int WP, int H, int W, float ix, float iy) {
     const float xf = floorf(ix), yf = floorf(iy);
-    const int x0 = min(max(asr_coord_to_int(xf), -2), W), y0 = min(max(asr_coord_to_int(yf), -2), H);
-    const unsigned off = (unsigned)((y0 + kGrPadY) * WP + (x0 + kGrPadX));
-    const asr_f2u top = *reinterpret_cast<const asr_f2u*>(plane + off);
-    const asr_f2u bot = *reinterpret_cast<const asr_f2u*>(plane + (off + (unsigned)WP));
+    // min(max(asr_coord_to_int(f), -2), size) with the clamp done on the float (exact: f is an integer, the bounds are small):
+    // one v_med3_f32 + one conversion per coordinate instead of four instructions; a NaN gives -2 either way (v_med3 returns
+    // the minimum of the other two, asr_coord_to_int -1e9).  The gathers are bound by VALU issue.
+    const int x0 = (int)__builtin_amdgcn_fmed3f(xf, -2.0f, (float)W), y0 = (int)__builtin_amdgcn_fmed3f(yf, -2.0f, (float)H);
+    // byte offset in 32 bits: the loads take the scalar plane base + this lane offset (no 64-bit vector arithmetic)
+    const unsigned off = __umul24((unsigned)(y0 + kGrPadY), (unsigned)(WP * 4)) + (unsigned)(x0 + kGrPadX) * 4u;   // both factors < 2^24
+    const char* const base = reinterpret_cast<const char*>(plane);
+    const asr_f2u top = *reinterpret_cast<const asr_f2u*>(base + off);
+    const asr_f2u bot = *reinterpret_cast<const asr_f2u*>(base + (off + (unsigned)(WP * 4)));
     const float wxl = (xf + 1.0f) - ix, wxh = ix - xf;
     const float vyf = wxl * top.x + wxh * top.y;
     const float vyc = wxl * bot.x + wxh * bot.y;
@@ -534,18 +539,14 @@ __global__ __launch_bounds__(256) void sr_backward_adam_kernel(
 // The copy index is uniform, so the transforms are scalar loads.  The copies are taken K at a time: when all K rotations
 // are affine (always, for the reference) the chunk is branch-free, so its 2K loads are in flight together and only the
 // final adds are a dependent chain.
-template <int K>
+template <int K, bool AFFINE>
 __device__ __forceinline__ float sr_gather_chunk(float g_df, const float* __restrict__ inv_rot_tf, const float* __restrict__ planes,
                                                  size_t plane, int WP, int H, int W, float fx, float fy) {
     AsrTf8 t[K];
-    bool affine = true;
 #pragma unroll
-    for (int u = 0; u < K; ++u) {
-        t[u] = asr_load_tf(inv_rot_tf + u * 8);
-        affine &= (t[u].c0 == 0.0f) & (t[u].c1 == 0.0f);
-    }
+    for (int u = 0; u < K; ++u) t[u] = asr_load_tf(inv_rot_tf + u * 8);
     float c[K];
-    if (affine) {
+    if (AFFINE) {
 #pragma unroll
         for (int u = 0; u < K; ++u) {
             float ix, iy;
@@ -564,6 +565,20 @@ __device__ __forceinline__ float sr_gather_chunk(float g_df, const float* __rest
     return g_df;
 }
 
+// flags[b] = 1 when every inverse rotation of image b is affine (c0 == c1 == 0: always, for the reference).  Evaluated once
+// per solve -- the transforms do not change between the iterations -- instead of by every wave for every chunk of copies
+// (two vector compares per copy and pixel in a kernel that is bound by VALU issue).
+__global__ __launch_bounds__(64) void sr_affine_flags_kernel(const float* __restrict__ inv_rot_tf, int* __restrict__ flags, int n) {
+    const int b = blockIdx.x;
+    bool ok = true;
+    for (int i = threadIdx.x; i < n; i += 64) {
+        const float* t = inv_rot_tf + ((int64_t)b * n + i) * 8;
+        ok = ok && t[6] == 0.0f && t[7] == 0.0f;
+    }
+    const bool all = __builtin_amdgcn_ballot_w64(!ok) == 0;
+    if (threadIdx.x == 0) flags[b] = all ? 1 : 0;
+}
+
 // The copies are taken in chunks [n0, n0 + cn) (one launch per chunk, the chunk's planes written by the K_gt launch before
 // it): the running sum of the data-term gradient crosses the launches through `acc` [batch, H, W] as a float32 -- the same
 // sequence of float32 additions, in copy order, as one pass over all copies, so the result does not depend on the chunking.
@@ -572,7 +587,8 @@ __global__ __launch_bounds__(256) void sr_backward_gather_kernel(
     const float* __restrict__ x, float* __restrict__ x_new, const float* __restrict__ gr_planes,
     const float* __restrict__ inv_rot_tf, float* __restrict__ m, float* __restrict__ v, float* __restrict__ vhat,
     const float* __restrict__ alphas, float* __restrict__ grad_out, SrDims d, float lambda_tv, float two_lambda_l2,
-    float lambda_l1, SrStep st, float* __restrict__ x_bordered_out, float* __restrict__ acc, int n0, int cn) {
+    float lambda_l1, SrStep st, float* __restrict__ x_bordered_out, float* __restrict__ acc, int n0, int cn,
+    const int* __restrict__ affine_flags) {
     const int X = blockIdx.x * 64 + threadIdx.x;
     const int Y = blockIdx.y * 4 + threadIdx.y;
     const int b = blockIdx.z;
@@ -585,9 +601,13 @@ __global__ __launch_bounds__(256) void sr_backward_gather_kernel(
     const int64_t o = ((int64_t)b * H + Y) * W + X;
     float g_df = (n0 == 0) ? 0.0f : acc[o];
     int n = 0;
-    for (; n + 8 <= cn; n += 8) g_df = sr_gather_chunk<8>(g_df, tfs + n * 8, planes + n * plane, plane, WP, H, W, fx, fy);
-    if (n + 4 <= cn) { g_df = sr_gather_chunk<4>(g_df, tfs + n * 8, planes + n * plane, plane, WP, H, W, fx, fy); n += 4; }
-    for (; n < cn; ++n) g_df = sr_gather_chunk<1>(g_df, tfs + n * 8, planes + n * plane, plane, WP, H, W, fx, fy);
+    if (affine_flags[b]) {       // the copies K at a time, branch-free: 2 K loads in flight, only the final adds are a chain
+        for (; n + 8 <= cn; n += 8) g_df = sr_gather_chunk<8, true>(g_df, tfs + n * 8, planes + n * plane, plane, WP, H, W, fx, fy);
+        if (n + 4 <= cn) { g_df = sr_gather_chunk<4, true>(g_df, tfs + n * 8, planes + n * plane, plane, WP, H, W, fx, fy); n += 4; }
+        for (; n < cn; ++n) g_df = sr_gather_chunk<1, true>(g_df, tfs + n * 8, planes + n * plane, plane, WP, H, W, fx, fy);
+    } else {
+        for (; n < cn; ++n) g_df = sr_gather_chunk<1, false>(g_df, tfs + n * 8, planes + n * plane, plane, WP, H, W, fx, fy);
+    }
     if (n0 + cn < d.n) { acc[o] = g_df; return; }
     sr_prior_and_update(x, x_new, m, v, vhat, alphas, grad_out, d, b, X, Y, g_df, lambda_tv, two_lambda_l2, lambda_l1, st,
                         x_bordered_out);
@@ -791,8 +811,9 @@ int sr_plane_chunk(int batch, int n, int H, int W, int requested) {
 size_t sr_workspace_bytes(int batch, int n, int H, int W, int h, int w, int chunk) {
     // residuals [batch*n, h, w] + the ping-pong x [batch, H, W] + the running data-term sum [batch, H, W] + the
     // zero-bordered planes [H + 4, W + 64]: G_R per copy of a chunk, x per image
+    // + one int per image: "all inverse rotations affine"
     return sizeof(float) * ((size_t)batch * n * h * w + 2 * (size_t)batch * H * W +
-                            ((size_t)batch * chunk + batch) * sr_gr_plane_elems(H, W));
+                            ((size_t)batch * chunk + batch) * sr_gr_plane_elems(H, W)) + sizeof(int) * (size_t)batch;
 }
 dim3 gather_grid(const SrDims& d) {
     return dim3((unsigned)asr_cdiv(d.W, 64), (unsigned)asr_cdiv(d.H, 4), (unsigned)d.batch);
@@ -973,6 +994,11 @@ extern "C" int asr_sr_solve_cfg_f32(float* x, const float* y, const float* rot_t
     float* const gr = acc + (size_t)batch * H * W;
     const SrGradTranslateKernel gr_kernel = sr_grad_translate_kernel_for(d.f);
     float* const xb = gr + (size_t)batch * chunk * sr_gr_plane_elems(H, W);   // bordered copy of the current x
+    int* const affine_flags = reinterpret_cast<int*>(xb + (size_t)batch * sr_gr_plane_elems(H, W));
+    if (num_iter > 0) {
+        hipLaunchKernelGGL(sr_affine_flags_kernel, dim3((unsigned)batch), dim3(64), 0, s, inv_rot_tf, affine_flags, n);
+        ASR_LAUNCH_CHECK();
+    }
     if (num_iter > 0) {   // the borders stay zero for the whole solve; the interiors are rewritten every iteration
         const size_t pe = sr_gr_plane_elems(H, W);
         ASR_HIP_CHECK(hipMemsetAsync(gr, 0, sizeof(float) * ((size_t)batch * chunk + batch) * pe, s));
@@ -995,7 +1021,7 @@ extern "C" int asr_sr_solve_cfg_f32(float* x, const float* y, const float* rot_t
             ASR_LAUNCH_CHECK();
             hipLaunchKernelGGL(sr_backward_gather_kernel, gather_grid(d), dim3(64, 4), 0, s, cur, nxt, gr, inv_rot_tf, m, v, vhat,
                                alphas + (size_t)it * batch, (float*)nullptr, d, lambda_tv, 2.0f * lambda_l2, lambda_l1, st, xb,
-                               acc, n0, cn);
+                               acc, n0, cn, affine_flags);
             ASR_LAUNCH_CHECK();
         }
         float* t = cur; cur = nxt; nxt = t;

@@ -41,17 +41,17 @@ def test_argument_validation_needs_no_gpu(lib):
     assert rc == -1 and b"null pointer" in lib.asr_last_error()
     rc = lib.asr_pwconv_packed_floats(728, 728)
     assert rc == 736 * 768
-    # residuals + ping-pong x + running data-term sum + bordered planes (one chunk of copies + x per image)
-    assert lib.asr_sr_solve_workspace_bytes(2, 3, 8, 8, 4, 4) == 4 * (2 * 3 * 16 + 2 * 2 * 64 + (2 * 3 + 2) * (8 + 4) * (8 + 64))
+    # residuals + ping-pong x + running data-term sum + bordered planes (one chunk of copies + x per image) + one flag per image
+    assert lib.asr_sr_solve_workspace_bytes(2, 3, 8, 8, 4, 4) == 4 * (2 * 3 * 16 + 2 * 2 * 64 + (2 * 3 + 2) * (8 + 4) * (8 + 64) + 2)
     import ctypes as C
     from asr_amd import ops
-    per = lambda chunk: 4 * (100 * 16 + 2 * 64 + (chunk + 1) * (8 + 4) * (8 + 64))
+    per = lambda chunk: 4 * (100 * 16 + 2 * 64 + (chunk + 1) * (8 + 4) * (8 + 64) + 1)
     assert lib.asr_sr_solve_workspace_bytes(1, 100, 8, 8, 4, 4) == per(100)           # default: all copies at once (< 1 GiB)
     assert lib.asr_sr_solve_workspace_bytes_cfg(1, 100, 8, 8, 4, 4, C.byref(ops.sr_config(plane_chunk=100))) == per(100)
     assert lib.asr_sr_solve_workspace_bytes_cfg(1, 100, 8, 8, 4, 4, C.byref(ops.sr_config(plane_chunk=7))) == per(7)
-    assert lib.asr_sr_solve_workspace_bytes_cfg(1, 200, 8, 8, 4, 4, C.byref(ops.sr_config(plane_chunk=29))) == 4 * (200 * 16 + 2 * 64 + (29 + 1) * 12 * 72)
+    assert lib.asr_sr_solve_workspace_bytes_cfg(1, 200, 8, 8, 4, 4, C.byref(ops.sr_config(plane_chunk=29))) == 4 * (200 * 16 + 2 * 64 + (29 + 1) * 12 * 72 + 1)
     # beyond 1 GiB of planes the default splits evenly: 2000 copies of 516 x 576 floats = 2.4 GB -> 3 chunks of 667
-    big = lambda chunk: 4 * (2000 * 128 * 128 + 2 * 512 * 512 + (chunk + 1) * 516 * 576)
+    big = lambda chunk: 4 * (2000 * 128 * 128 + 2 * 512 * 512 + (chunk + 1) * 516 * 576 + 1)
     assert lib.asr_sr_solve_workspace_bytes(1, 2000, 512, 512, 128, 128) == big(667)
 
 
