@@ -64,10 +64,12 @@ __device__ __forceinline__ float sr_bilinear_bordered(const float* __restrict__ 
     // the minimum of the other two, asr_coord_to_int -1e9).  The gathers are bound by VALU issue.
     const int x0 = (int)__builtin_amdgcn_fmed3f(xf, -2.0f, (float)W), y0 = (int)__builtin_amdgcn_fmed3f(yf, -2.0f, (float)H);
     // byte offset in 32 bits: the loads take the scalar plane base + this lane offset (no 64-bit vector arithmetic)
-    const unsigned off = __umul24((unsigned)(y0 + kGrPadY), (unsigned)(WP * 4)) + (unsigned)(x0 + kGrPadX) * 4u;   // both factors < 2^24
+    // (y0 + pad) * row bytes + (x0 + pad) * 4 as one 24-bit multiply-add (|y0|, row bytes < 2^23) and one shift-add
+    const unsigned off = (unsigned)(__mul24(y0, WP * 4) + (kGrPadY * WP * 4 + kGrPadX * 4) + x0 * 4);
     const char* const base = reinterpret_cast<const char*>(plane);
+    const char* const base_next = base + WP * 4;               // the next row through a second SCALAR base, not a lane add
     const asr_f2u top = *reinterpret_cast<const asr_f2u*>(base + off);
-    const asr_f2u bot = *reinterpret_cast<const asr_f2u*>(base + (off + (unsigned)(WP * 4)));
+    const asr_f2u bot = *reinterpret_cast<const asr_f2u*>(base_next + off);
     const float wxl = (xf + 1.0f) - ix, wxh = ix - xf;
     const float vyf = wxl * top.x + wxh * top.y;
     const float vyc = wxl * bot.x + wxh * bot.y;
