@@ -428,34 +428,41 @@ __global__ __launch_bounds__(768, 3) void pw_gemm_f16x3_pre_ring_kernel(PwArgs p
     if (wave >= 8) {
         // ---- loader wave w: pieces 8 w .. 8 w + 7 of every unit ------------------------------------------------------
         const int first = (wave - 8) * PIECES;
-        const char* src_a[PIECES];
-        const char* src_b[PIECES];
+        // Source address of a piece = a base that is the same for the whole wave (scalar registers; advanced per K-step by
+        // scalar adds) + a 32-bit byte offset per lane, fixed for the whole tile: the request loop then holds no vector
+        // instruction at all (a 64-bit vector add per piece before) -- vector instructions of the loader waves take issue
+        // slots from the MFMA waves of their SIMD (profiles/r03_gemm_loader_valu_experiment.txt).
+        unsigned off_a[PIECES], off_b[PIECES];
         const long long plane_bytes = (long long)p.Kpad * p.Npad * 2;
         const long long kstep_b = (long long)4 * p.Npad * 16;     // byte advance per K-step (A: 128)
+        const long long m0 = (long long)tile_m * BM;
+        const char* const base_a = reinterpret_cast<const char*>(p.x) + m0 * p.ldx * 128;
+        const char* const base_b = reinterpret_cast<const char*>(p.wp) + (long long)tile_n * BN * 16;
 #pragma unroll
         for (int j = 0; j < PIECES; ++j) {
             const int pi = first + j;
             {   // A: (row q >> 3, LDS slot q & 7 holding global slot ^ swizzle)
                 const int q = pi * 64 + lane, row = q >> 3, slot = (q & 7) ^ ((row >> 1) & 7);
-                long long m = (long long)tile_m * BM + row;
-                if (m >= p.M) m = p.M - 1;                      // rows past the end re-read the last row; never stored
-                src_a[j] = reinterpret_cast<const char*>(p.x) + (m * p.ldx) * 128 + slot * 16;
+                long long r = row;
+                if (m0 + r >= p.M) r = p.M - 1 - m0;             // rows past the end re-read the last row; never stored
+                off_a[j] = (unsigned)(r * p.ldx * 128 + slot * 16);
             }
             {   // B: plane (hi, lo), k-octet, column
                 const int qb = pi * 64 + lane, plane = qb >> 10, r = qb & 1023, oct = r >> 8, col = r & 255;
-                src_b[j] = reinterpret_cast<const char*>(p.wp) + plane * plane_bytes +
-                           (((long long)oct * p.Npad) + (long long)tile_n * BN + col) * 16;
+                off_b[j] = (unsigned)(plane * plane_bytes + ((long long)oct * p.Npad + col) * 16);
             }
         }
         auto issue_a = [&](int kt, int slot) {
             char* const dst = lds + slot * UNIT + first * 1024;
+            const char* const src = base_a + (long long)kt * 128;
 #pragma unroll
-            for (int j = 0; j < PIECES; ++j) glds16(src_a[j] + (long long)kt * 128, dst + j * 1024);
+            for (int j = 0; j < PIECES; ++j) glds16_sbase(src, off_a[j], dst + j * 1024);
         };
         auto issue_b = [&](int kt, int slot) {
             char* const dst = lds + slot * UNIT + first * 1024;
+            const char* const src = base_b + kt * kstep_b;
 #pragma unroll
-            for (int j = 0; j < PIECES; ++j) glds16(src_b[j] + kt * kstep_b, dst + j * 1024);
+            for (int j = 0; j < PIECES; ++j) glds16_sbase(src, off_b[j], dst + j * 1024);
         };
         issue_a(0, 0);
         issue_b(0, 1);
@@ -487,7 +494,7 @@ __global__ __launch_bounds__(768, 3) void pw_gemm_f16x3_pre_ring_kernel(PwArgs p
                 if (m >= p.M) m = p.M - 1;                             // never used
                 int col = tile_n * BN + ((lane ^ (r & 15)) << 2);
                 if (col + 3 >= p.N) col = 0;                           // columns past N: any valid quad, never used
-                glds16(p.res + m * p.ldres + col, lds + ((r >> 5) ? slot_h1 : slot_h0) * UNIT + (r & 31) * 1024);
+                glds16_sbase(p.res + m * p.ldres, (unsigned)col * 4u, lds + ((r >> 5) ? slot_h1 : slot_h0) * UNIT + (r & 31) * 1024);   // row base: scalar
             }
         };
         for (int kt = 0; kt < KT; ++kt) {
@@ -502,7 +509,7 @@ __global__ __launch_bounds__(768, 3) void pw_gemm_f16x3_pre_ring_kernel(PwArgs p
                     if (p.bias && wave == 8) {
                         int col = tile_n * BN + lane * 4;
                         if (col + 3 >= p.N) col = 0;
-                        glds16(p.bias + col, lds + slot_a * UNIT);
+                        glds16_sbase(p.bias, (unsigned)col * 4u, lds + slot_a * UNIT);
                     }
                     if (res_dma) issue_res(0, slot_b - 1 < 0 ? RING - 1 : slot_b - 1, slot_b);
                 }

@@ -310,6 +310,17 @@ __device__ __forceinline__ void glds16(const void* g, void* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((asr_gbl_ptr)g, (asr_lds_ptr)lds_wave_base, 16, 0, 0);
 }
 
+// The same request with the source as a wave-uniform base (scalar register pair) + a 32-bit byte offset per lane: the
+// compiler's builtin always takes a 64-bit vector address (one v_lshl_add_u64 per request).  M0 = LDS byte address of the
+// wave's destination; lane l lands at M0 + 16 l.
+__device__ __forceinline__ void glds16_sbase(const void* uniform_base, unsigned lane_byte_offset, void* lds_wave_base) {
+    const unsigned m0v = (unsigned)(unsigned long long)(asr_lds_ptr)lds_wave_base;
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                 :
+                 : "v"(lane_byte_offset), "s"(uniform_base), "s"(m0v)
+                 : "memory", "m0");
+}
+
 template <typename F, int... I>
 __device__ __forceinline__ void asr_static_for_impl(F& f, std::integer_sequence<int, I...>) {
     (f(std::integral_constant<int, I>{}), ...);
