@@ -96,6 +96,29 @@ __device__ __forceinline__ void asr_split_f16(float v, _Float16& hi, _Float16& l
     lo = (_Float16)__builtin_fminf(__builtin_fmaxf(v - (float)hi, -65504.0f), 65504.0f);
 }
 
+// The same split for four values at once in a wave that has switched on the hardware's f16 overflow clamp
+// (asr_enable_f16_saturation, once at kernel entry): the conversions themselves saturate at +-65504, so the two clamps per
+// value go, and the packed converts take two values per instruction -- 10 vector instructions for four values instead of
+// 24 (28 when the values come straight from memory: the compiler first quiets a possible signalling NaN).  It matters where
+// the split shares a SIMD with MFMAs: vector instructions of co-resident waves take issue slots from the matrix pipe
+// (profiles/r03_gemm_loader_valu_experiment.txt).  Same halves as asr_split_f16 for every finite input; a true infinity
+// stays one (MODE.FP16_OVFL preserves INF), where asr_split_f16 gives 65504.
+typedef float asr_f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 asr_f16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void asr_enable_f16_saturation() {
+    __builtin_amdgcn_s_setreg(1 | (23 << 6), 1);   // hwreg(HW_REG_MODE, 23, 1) = FP16_OVFL: an overflowing f16 result clamps to +-MAX
+}
+// hi01, hi23, lo01, lo23: two halves per dword, element order preserved
+__device__ __forceinline__ void asr_split4_f16_saturating_mode(float v0, float v1, float v2, float v3, unsigned int& hi01,
+                                                               unsigned int& hi23, unsigned int& lo01, unsigned int& lo23) {
+    const asr_f32x2 a = {v0, v1}, b = {v2, v3};
+    const asr_f16x2 ha = __builtin_convertvector(a, asr_f16x2), hb = __builtin_convertvector(b, asr_f16x2);
+    const asr_f32x2 ra = a - __builtin_convertvector(ha, asr_f32x2), rb = b - __builtin_convertvector(hb, asr_f32x2);
+    const asr_f16x2 la = __builtin_convertvector(ra, asr_f16x2), lb = __builtin_convertvector(rb, asr_f16x2);
+    hi01 = __builtin_bit_cast(unsigned int, ha); hi23 = __builtin_bit_cast(unsigned int, hb);
+    lo01 = __builtin_bit_cast(unsigned int, la); lo23 = __builtin_bit_cast(unsigned int, lb);
+}
+
 // wave64 sum via DPP-free shuffles.
 __device__ __forceinline__ float asr_wave_sum(float v) {
 #pragma unroll

@@ -182,15 +182,17 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwArgs p) {
 // weights ([K/8][Npad][8] per plane) -- 32 KB, single buffer, 2 barriers per K-tile.
 // =================================================================================================
 
+// in a kernel that has called asr_enable_f16_saturation()
 __device__ __forceinline__ void split_f16x8(const f32x4& a, const f32x4& b, f16x8& hi, f16x8& lo) {
-    const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        _Float16 h, l;
-        asr_split_f16(v[j], h, l);
-        hi[j] = h;
-        lo[j] = l;
-    }
+    typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+    u32x4_t h, l;
+    unsigned int h0, h1, l0, l1;
+    asr_split4_f16_saturating_mode(a.x, a.y, a.z, a.w, h0, h1, l0, l1);
+    h.x = h0; h.y = h1; l.x = l0; l.y = l1;
+    asr_split4_f16_saturating_mode(b.x, b.y, b.z, b.w, h0, h1, l0, l1);
+    h.z = h0; h.w = h1; l.z = l0; l.w = l1;
+    hi = __builtin_bit_cast(f16x8, h);
+    lo = __builtin_bit_cast(f16x8, l);
 }
 
 template <int WM, int WN, int TM, int TN, bool CONV>
@@ -199,6 +201,7 @@ __global__ __launch_bounds__(WM * WN * 64) void pw_gemm_f16x3_kernel(PwArgs p) {
     constexpr int PA = BM * 4 / NT;                    // (row, 32-byte k-slot) items of the A tile per thread
     constexpr int PB = BN * 4 / NT;                    // (k-octet, column) items of the B tile per thread and plane
     static_assert((BM * 4) % NT == 0 && (BN * 4) % NT == 0 && (BN & (BN - 1)) == 0, "tile / thread-count mismatch");
+    asr_enable_f16_saturation();                       // the A split's conversions saturate in hardware (split_f16x8)
     // dynamic LDS = max(stages, epilogue staging of WM*WN waves x 32 x TN*32 floats), sized by the launcher
     extern __shared__ __attribute__((aligned(16))) float smem[];
     _Float16* const sAh = reinterpret_cast<_Float16*>(smem);   // [BM rows][32]          (+ stage offset)

@@ -132,10 +132,29 @@ __global__ __launch_bounds__(256) void conv3x3_stem_kernel(const float* __restri
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// 16 values -> hi / lo halves as two f16x8 each (element order preserved), in a kernel that has called
+// asr_enable_f16_saturation(): packed saturating conversions instead of clamp + convert per value (asr_common.h)
+__device__ __forceinline__ void split16_f16(const float (&a)[16], f16x8 (&hi)[2], f16x8 (&lo)[2]) {
+    typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        u32x4_t h, l;
+        unsigned int h0, h1, l0, l1;
+        asr_split4_f16_saturating_mode(a[8 * s + 0], a[8 * s + 1], a[8 * s + 2], a[8 * s + 3], h0, h1, l0, l1);
+        h.x = h0; h.y = h1; l.x = l0; l.y = l1;
+        asr_split4_f16_saturating_mode(a[8 * s + 4], a[8 * s + 5], a[8 * s + 6], a[8 * s + 7], h0, h1, l0, l1);
+        h.z = h0; h.w = h1; l.z = l0; l.w = l1;
+        hi[s] = __builtin_bit_cast(f16x8, h);
+        lo[s] = __builtin_bit_cast(f16x8, l);
+    }
+}
+
+
 __global__ __launch_bounds__(256) void conv3x3_stem_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                                 const float* __restrict__ bias, float* __restrict__ y, int batch,
                                                                 int h_in, int w_in, int stride, int pad_top, int pad_left,
                                                                 int h_out, int w_out, int ldx, int ldy, int relu) {
+    asr_enable_f16_saturation();                              // the splits below convert with the hardware's f16 clamp
     constexpr int COUT = 32, NE = 27;
     const int lane = threadIdx.x & 63, l32 = lane & 31, hh = lane >> 5;
     // k slot (s, j) of this lane half holds input element e = 16 s + 8 hh + j, e = (ky * 3 + kx) * 3 + ci
@@ -175,13 +194,7 @@ __global__ __launch_bounds__(256) void conv3x3_stem_mfma_kernel(const float* __r
             a[k] = in ? v : 0.0f;
         }
         f16x8 ah[2], al[2];
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            _Float16 hi, lo;
-            asr_split_f16(a[k], hi, lo);
-            ah[k >> 3][k & 7] = hi;
-            al[k >> 3][k & 7] = lo;
-        }
+        split16_f16(a, ah, al);
         f32x16 acc;
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
@@ -230,6 +243,7 @@ __global__ __launch_bounds__(512) void entry_stem_fused_kernel(const float* __re
                                                                const float* __restrict__ b1, const _Float16* __restrict__ w2p,
                                                                const float* __restrict__ b2, float* __restrict__ y, int batch,
                                                                int h_in, int w_in, int h1, int w1d, int ldx, int ldy, int npad2) {
+    asr_enable_f16_saturation();                              // the splits below convert with the hardware's f16 clamp
     extern __shared__ __attribute__((aligned(16))) char es_lds[];
     char* const T1 = es_lds;
     char* const Bh = es_lds + ES_T1_BYTES;
@@ -301,13 +315,7 @@ __global__ __launch_bounds__(512) void entry_stem_fused_kernel(const float* __re
     };
     auto finish = [&](const Gathered& r, char* T1) {
         f16x8 xh[2], xl[2];
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            _Float16 hi, lo;
-            asr_split_f16(r.a[k], hi, lo);
-            xh[k >> 3][k & 7] = hi;
-            xl[k >> 3][k & 7] = lo;
-        }
+        split16_f16(r.a, xh, xl);
         f32x16 acc;
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
@@ -322,17 +330,16 @@ __global__ __launch_bounds__(512) void entry_stem_fused_kernel(const float* __re
             const int swz = (r.line >> 1) & 7;
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {                   // registers 4 g4 .. 4 g4 + 3 = channels 8 g4 + 4 hh + 0..3
-                f16x4 hi, lo;
+                float v[4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float v = r.in_map ? fmaxf(acc[4 * g4 + i] + b1v[4 * g4 + i], 0.0f) : 0.0f;
-                    _Float16 h, l;
-                    asr_split_f16(v, h, l);
-                    hi[i] = h;
-                    lo[i] = l;
-                }
-                *reinterpret_cast<f16x4*>(line + ((g4 ^ swz) << 4) + hh * 8) = hi;
-                *reinterpret_cast<f16x4*>(line + (((4 + g4) ^ swz) << 4) + hh * 8) = lo;
+                for (int i = 0; i < 4; ++i) v[i] = r.in_map ? fmaxf(acc[4 * g4 + i] + b1v[4 * g4 + i], 0.0f) : 0.0f;
+                typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+                u32x2_t hi, lo;
+                unsigned int h0, h1, l0, l1;
+                asr_split4_f16_saturating_mode(v[0], v[1], v[2], v[3], h0, h1, l0, l1);
+                hi.x = h0; hi.y = h1; lo.x = l0; lo.y = l1;
+                *reinterpret_cast<u32x2_t*>(line + ((g4 ^ swz) << 4) + hh * 8) = hi;
+                *reinterpret_cast<u32x2_t*>(line + (((4 + g4) ^ swz) << 4) + hh * 8) = lo;
             }
         }
     };
