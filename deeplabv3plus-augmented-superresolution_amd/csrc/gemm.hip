@@ -890,6 +890,9 @@ extern "C" int asr_pwconv_mfma_f16x3_presplit(const void* x_split, const float* 
     ASR_REQUIRE(ldx_chunks * BK >= a.Kpad, "asr_pwconv_mfma_f16x3_presplit: ldx_chunks * 32 < ceil32(k)");
     ASR_UNSUPPORTED(a.Npad % 256 != 0, "asr_pwconv_mfma_f16x3_presplit: ceil128(n) must be a multiple of 256 (n=%d)", n);
     ASR_UNSUPPORTED(reinterpret_cast<uintptr_t>(x_split) & 127, "asr_pwconv_mfma_f16x3_presplit: x_split must be 128-byte aligned");
+    // the loader waves address a tile's operands by 32-bit byte offsets from a per-tile base
+    ASR_UNSUPPORTED((long long)ldx_chunks * 128 * 256 >= (1LL << 32) || (long long)a.Kpad * a.Npad * 4 + (long long)a.Npad * 64 >= (1LL << 32),
+                    "asr_pwconv_mfma_f16x3_presplit: operands too large for 32-bit tile offsets (k=%d n=%d ldx_chunks=%d)", k, n, ldx_chunks);
     constexpr int bm = 256, bn = 256;
     a.tiles_n = (int)asr_cdiv(n, bn);
     const long long nwg = asr_cdiv(m, bm) * a.tiles_n;
