@@ -41,6 +41,10 @@ def test_argument_validation_needs_no_gpu(lib):
     assert rc == -1 and b"null pointer" in lib.asr_last_error()
     rc = lib.asr_pwconv_packed_floats(728, 728)
     assert rc == 736 * 768
+    # the pre-split GEMM addresses a tile's operands by 32-bit offsets: operands beyond that are refused, not wrapped
+    fake = 1 << 20                                               # non-null, 128-byte aligned; never dereferenced on the host
+    rc = lib.asr_pwconv_mfma_f16x3_presplit(fake, fake, None, None, fake, 1024, 40960, 40960, 1280, 40960, 0, 0, None)
+    assert rc == -2 and b"32-bit tile offsets" in lib.asr_last_error()
     # residuals + ping-pong x + running data-term sum + bordered planes (one chunk of copies + x per image) + one flag per image
     assert lib.asr_sr_solve_workspace_bytes(2, 3, 8, 8, 4, 4) == 4 * (2 * 3 * 16 + 2 * 2 * 64 + (2 * 3 + 2) * (8 + 4) * (8 + 64) + 2)
     import ctypes as C
