@@ -28,7 +28,7 @@ SOURCES = [
     ("warp.hip", ["-ffp-contract=off"]),
     ("sr.hip", ["-ffp-contract=off"]),
     ("reduce.hip", ["-ffp-contract=off"]),
-    ("gemm.hip", []),
+    ("gemm.hip", ["-Wno-inline-asm"]),     # glds16_sbase names m0 as clobbered (it is: the LDS-DMA destination); clang flags any reserved register
     ("dwconv.hip", []),
     ("layers.hip", []),
     ("sepconv.hip", []),

@@ -414,7 +414,7 @@ __global__ __launch_bounds__(WM * WN * 64) void pw_gemm_f16x3_kernel(PwArgs p) {
 // per accumulator as every earlier form => bit-identical results.
 // =================================================================================================
 __global__ __launch_bounds__(768, 3) void pw_gemm_f16x3_pre_ring_kernel(PwArgs p) {
-    constexpr int BM = 256, BN = 256, WN = 2, RT = 4, CT = 8;
+    constexpr int BM = 256, BN = 256, RT = 4, CT = 8;
     constexpr int UNIT = 32 * 1024, RING = 5, B_PLANE = 4 * BN * 16;      // B unit = hi plane (16 KB) + lo plane
     constexpr int PIECES = 8;                                  // 1 KiB pieces per loader wave and unit (4 loaders x 8 = 32 KB)
     static_assert(BM * 128 == UNIT && 2 * B_PLANE == UNIT, "unit size");
@@ -663,6 +663,229 @@ __global__ __launch_bounds__(768, 3) void pw_gemm_f16x3_pre_ring_kernel(PwArgs p
 }
 
 
+// The same kernel as a PERSISTENT walk for launches without a residual (with one, the epilogue's staging owns the free slots:
+// built and measured equal to the one-tile kernel, 0 ... -2 %, not kept): a workgroup takes tiles wg, wg + G, wg + 2 G, ...
+// and the ring runs on across the tile boundary -- unit u of the next tile lives where unit 2 KT + u of the current one
+// would -- so that the next tile's units 0 and 1 are requested in the current tile's LAST K-step (whose three free slots
+// held only the bias row) and have landed long before its epilogue ends: no prologue (and no workgroup dispatch) between
+// tiles.  One barrier after the epilogue tells the loaders that the bias row is no longer read, then unit 2 of the next
+// tile takes its slot.  Same MFMA sequence per accumulator, same epilogue: bit-identical to the one-tile kernel.
+__global__ __launch_bounds__(768, 3) void pw_gemm_f16x3_pre_ring_persist_kernel(PwArgs p, int ntiles) {
+    constexpr int BM = 256, BN = 256, RT = 4, CT = 8;
+    constexpr int UNIT = 32 * 1024, RING = 5, B_PLANE = 4 * BN * 16;      // B unit = hi plane (16 KB) + lo plane
+    constexpr int PIECES = 8;                                  // 1 KiB pieces per loader wave and unit (4 loaders x 8 = 32 KB)
+    static_assert(BM * 128 == UNIT && 2 * B_PLANE == UNIT, "unit size");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    char* const lds = reinterpret_cast<char*>(smem);
+
+    const int G = gridDim.x, wg = blockIdx.x;                 // G % 8 == 0: every tile of a workgroup has its XCD (wg & 7)
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int KT = p.Kpad / BK;
+    auto tile_of = [&](int t, int& tile_m, int& tile_n) {     // the bijective XCD remap of the one-tile kernel, over all tiles
+        const int q8 = ntiles >> 3, r8 = ntiles & 7, xcd = t & 7;
+        const int lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (t >> 3);
+        tile_m = lid / p.tiles_n;
+        tile_n = lid % p.tiles_n;
+    };
+
+    if (wave >= 8) {
+        // ---- loader wave w: pieces 8 w .. 8 w + 7 of every unit ------------------------------------------------------
+        const int first = (wave - 8) * PIECES;
+        unsigned off_a[PIECES], off_b[PIECES];
+        const long long plane_bytes = (long long)p.Kpad * p.Npad * 2;
+        const long long kstep_b = (long long)4 * p.Npad * 16;     // byte advance per K-step (A: 128)
+        const char* base_a = nullptr;
+        const char* base_b = nullptr;
+        int tile_m = 0, tile_n = 0;
+        auto setup = [&](int t) {                                 // scalar bases + 32-bit lane offsets of tile t (see the one-tile kernel)
+            tile_of(t, tile_m, tile_n);
+            const long long m0 = (long long)tile_m * BM;
+            base_a = reinterpret_cast<const char*>(p.x) + m0 * p.ldx * 128;
+            base_b = reinterpret_cast<const char*>(p.wp) + (long long)tile_n * BN * 16;
+#pragma unroll
+            for (int j = 0; j < PIECES; ++j) {
+                const int pi = first + j;
+                {
+                    const int q = pi * 64 + lane, row = q >> 3, slot = (q & 7) ^ ((row >> 1) & 7);
+                    long long r = row;
+                    if (m0 + r >= p.M) r = p.M - 1 - m0;
+                    off_a[j] = (unsigned)(r * p.ldx * 128 + slot * 16);
+                }
+                {
+                    const int qb = pi * 64 + lane, plane = qb >> 10, r = qb & 1023, oct = r >> 8, col = r & 255;
+                    off_b[j] = (unsigned)(plane * plane_bytes + ((long long)oct * p.Npad + col) * 16);
+                }
+            }
+        };
+        auto issue_a = [&](int kt, int slot) {
+            char* const dst = lds + slot * UNIT + first * 1024;
+            const char* const src = base_a + (long long)kt * 128;
+#pragma unroll
+            for (int j = 0; j < PIECES; ++j) glds16_sbase(src, off_a[j], dst + j * 1024);
+        };
+        auto issue_b = [&](int kt, int slot) {
+            char* const dst = lds + slot * UNIT + first * 1024;
+            const char* const src = base_b + kt * kstep_b;
+#pragma unroll
+            for (int j = 0; j < PIECES; ++j) glds16_sbase(src, off_b[j], dst + j * 1024);
+        };
+        auto ring = [&](int v) { return v % RING; };
+        const bool ep_fast = pw_ep_fast(p);
+        int t = wg, s0 = 0;                                      // unit u of the current tile lives in slot (s0 + u) % RING
+        setup(t);
+        issue_a(0, 0);                                           // only the FIRST tile has a prologue
+        issue_b(0, 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        for (; t < ntiles; t += G) {
+            const bool has_next = t + G < ntiles;
+            int slot_b = ring(s0 + 3), slot_a = ring(s0 + 4);    // slots of units 2 kt + 3 and 2 kt + 4
+            for (int kt = 0; kt < KT; ++kt) {
+                // A_1 is requested here, not with A_0 / B_0: its slot held the previous tile's bias row until the barrier
+                // that ended that tile's epilogue
+                if (kt == 0) issue_a(1, ring(s0 + 2));
+                if (kt + 1 < KT) issue_b(kt + 1, slot_b);
+                if (kt + 2 < KT) {
+                    issue_a(kt + 2, slot_a);
+                    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // all but A_{kt+2}: the operands of step kt + 1 are in
+                } else {
+                    if (kt + 1 == KT) {
+                        // last K-step: no more units of this tile.  Of the three free slots, (2 KT + 2) takes the bias row as in
+                        // the one-tile kernel, and (2 KT), (2 KT + 1) take units 0 and 1 of the NEXT tile: they land under this
+                        // tile's last MFMAs and its epilogue, the next tile has no prologue.
+                        if (ep_fast && p.bias && wave == 8) {
+                            int col = tile_n * BN + lane * 4;
+                            if (col + 3 >= p.N) col = 0;
+                            glds16_sbase(p.bias, (unsigned)col * 4u, lds + slot_a * UNIT);
+                        }
+                        if (has_next) {
+                            setup(t + G);
+                            issue_a(0, slot_b - 1 < 0 ? RING - 1 : slot_b - 1);
+                            issue_b(0, slot_b);
+                            // the epilogue may start when this tile's operands and the bias row are in: everything but the
+                            // 16 youngest requests (the next tile's units, waited for below)
+                            asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                        } else {
+                            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        }
+                    } else {
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    }
+                }
+                __builtin_amdgcn_s_barrier();
+                if (kt + 1 < KT) {
+                    slot_b = slot_b + 2 >= RING ? slot_b + 2 - RING : slot_b + 2;
+                    slot_a = slot_a + 2 >= RING ? slot_a + 2 - RING : slot_a + 2;
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // units 0 and 1 of the next tile are in
+            __builtin_amdgcn_s_barrier();                        // the MFMA waves are done with the bias row (epilogue)
+            s0 = ring(s0 + 2 * KT);
+        }
+        return;
+    }
+
+    // ---- MFMA wave ------------------------------------------------------------------------------------------------
+    // Waves w and w + 4 share a SIMD: they get the two column halves of the same row block, so that a padded last N-tile
+    // (N = 728: 2 of the 8 column tiles of the right half are pure padding, and are skipped) shortens every SIMD's K-step alike.
+    const int wm = wave & 3, wn = wave >> 2;
+    __builtin_amdgcn_s_barrier();                              // units 0 and 1 of the first tile landed (the loaders waited for them)
+    int slot = 0;                                              // slot of unit 2 kt (A); B sits in the next slot of the ring; runs on across tiles
+    for (int t = wg; t < ntiles; t += G) {
+    int tile_m, tile_n;
+    tile_of(t, tile_m, tile_n);
+    const int ct_valid = min(CT, max(0, (p.N - (tile_n * BN + wn * (CT * 16)) + 15) >> 4));   // column tiles holding real columns
+    f32x4 acc[RT][CT];
+#pragma unroll
+    for (int i = 0; i < RT; ++i)
+#pragma unroll
+        for (int j = 0; j < CT; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
+
+    auto kloop = [&](auto CTV_) {
+        constexpr int CTV = decltype(CTV_)::value;             // column tiles computed by this wave (even; 8 = all)
+        for (int kt = 0; kt < KT; ++kt) {
+            const int off_a = slot * UNIT, off_b = (slot + 1 >= RING ? 0 : slot + 1) * UNIT;    // wave-uniform
+            slot = slot + 2 >= RING ? slot + 2 - RING : slot + 2;
+            // The three lane-dependent byte offsets of the fragment reads (A hi, A lo, B) are RE-DERIVED from the lane id in
+            // every K-step (a dozen VALU instructions against ~3000 cycles of MFMAs): the accumulators and fragments leave
+            // no registers to keep them in, and the compiler would otherwise hoist them out of the loop and spill them --
+            // three scratch reloads with their waits at the head of every K-step.  The empty asm makes the lane id opaque.
+            int ln = lane;
+            asm volatile("" : "+v"(ln));
+            const int l16 = ln & 15, oct = ln >> 4;            // A: row = l16, k = 8 oct ..; B: column = l16, same k
+            // row tile t of this wave starts at row (wm * RT + t) * 16: (row >> 1) & 7 == (l16 >> 1) & 7 for every t
+            const int swz = (l16 >> 1) & 7;
+            const int a_row = off_a + (wm * RT * 16 + l16) * 128;
+            const int a_hi = a_row + ((oct ^ swz) << 4), a_lo = a_row + (((4 + oct) ^ swz) << 4);
+            const int b_col = off_b + (oct * BN + wn * CT * 16 + l16) * 16;
+            // 2 halves x CTV column tiles = 2 CTV groups of 6 MFMAs (16 groups for a full tile); the fragments of group g + 1 are requested before the MFMAs of
+            // group g (one B double buffer, the A pair of the second half is requested under the last group of the first),
+            // and a scheduling barrier per group keeps the compiler from hoisting every read to the top (it would need 160
+            // fragment registers and spill).
+            f16x8 ah[2], al[2], bh[2], bl[2];
+            auto read_a = [&](int half, int i) {                   // hi / lo fragments of row tile 2 * half + i
+                ah[i] = *reinterpret_cast<const f16x8*>(lds + a_hi + (2 * half + i) * 2048);
+                al[i] = *reinterpret_cast<const f16x8*>(lds + a_lo + (2 * half + i) * 2048);
+            };
+            auto read_b = [&](int j, int buf) {
+                bh[buf] = *reinterpret_cast<const f16x8*>(lds + b_col + j * 256);
+                bl[buf] = *reinterpret_cast<const f16x8*>(lds + b_col + j * 256 + B_PLANE);
+            };
+            read_a(0, 0);
+            read_a(0, 1);
+            read_b(0, 0);
+            auto group = [&](auto G) {
+                constexpr int g = decltype(G)::value, half = g / CTV, j = g % CTV;
+                constexpr bool last_of_half0 = g == CTV - 1;
+                if (g + 1 < 2 * CTV) read_b((g + 1) % CTV, (g + 1) & 1);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    f32x4& a4 = acc[2 * half + i][j];
+                    // the WEIGHTS fragment is the first operand: the MFMA then yields the transposed 16 x 16 tile -- lane
+                    // (l16, q4) holds row l16 and the four CONSECUTIVE columns 4 q4 .. 4 q4 + 3 -- which the epilogue
+                    // stores with one 16-byte store per register quad, no LDS transposition.  Same products (x * w
+                    // commutes), same k order, same accumulation sequence as the untransposed form: bit-identical.
+                    a4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[g & 1], al[i], a4, 0, 0, 0);
+                    a4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[g & 1], ah[i], a4, 0, 0, 0);
+                    a4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[g & 1], ah[i], a4, 0, 0, 0);
+                    if (last_of_half0) read_a(1, i);               // the second half's row tile into the registers just consumed
+                }
+                // order inside the group: the next group's fragment reads first, then the MFMAs (the A refills behind their rows)
+                if (g + 1 < 2 * CTV) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+                if (last_of_half0) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+                if (last_of_half0) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            asr_static_for<2 * CTV>(group);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // this wave's reads of the two units are done
+            __builtin_amdgcn_s_barrier();
+        }
+    };
+    if (ct_valid > 6) kloop(std::integral_constant<int, 8>{});
+    else if (ct_valid > 4) kloop(std::integral_constant<int, 6>{});
+    else if (ct_valid > 2) kloop(std::integral_constant<int, 4>{});
+    else kloop(std::integral_constant<int, 2>{});
+    // ---- epilogue: bias, ReLU, residual, store -- no vector-memory LOAD and no LDS transposition -------------------------
+    // The transposed accumulators go straight out: per register quad one 16-byte store, 64 contiguous bytes per row and
+    // instruction (the next column tile completes the 128-byte line).  What the epilogue has to READ -- the bias row and,
+    // in the last layer of a block, the residual tile -- was put into LDS by the loader waves (above), so the only waits of
+    // these waves are lgkmcnt waits on ds_reads: on gfx9 one vmcnt counter counts loads AND stores in issue order, and a
+    // wave that waits for a residual load also waits for every older store to reach a memory system that all 256 CUs are
+    // writing to at once (the direct-load form of this epilogue measured 1.16x the staged one with a residual,
+    // profiles/r02_gemm_epilogue_experiments.txt #4; without one 0.95x).  `slot` = the first free slot of the last K-step.
+    pw_epilogue16_ring<RT, CT>(p, acc, lds, slot, UNIT, RING, (long long)tile_m * BM + wm * (RT * 16), tile_n * BN + wn * (CT * 16),
+                              wm, wn);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // this wave's reads of the bias row are done
+    __builtin_amdgcn_s_barrier();                              // ... and everybody's: the loaders may overwrite its slot (A_1 of the next tile)
+    }
+}
+
+
+
 // w [K][N] f32 -> two half planes [Kpad/8][Npad][8] (hi then lo), zero padded
 __global__ __launch_bounds__(256) void pack_weights_f16x3_kernel(const float* __restrict__ w, _Float16* __restrict__ wp, int K,
                                                                  int N, int Kpad, int Npad) {
@@ -898,6 +1121,23 @@ extern "C" int asr_pwconv_mfma_f16x3_presplit(const void* x_split, const float* 
     const long long nwg = asr_cdiv(m, bm) * a.tiles_n;
     ASR_REQUIRE(nwg <= 0x7fffffffLL, "asr_pwconv_mfma_f16x3_presplit: grid too large");
     constexpr size_t lds = 5 * 32 * 1024;                      // the five-unit ring: all of the CU's LDS
+    // Without a residual (whose staging needs the ring's free slots in the epilogue) and with more tiles than CUs the
+    // tiles are walked by one persistent workgroup per CU: the next tile's first units land under the current epilogue.
+    static int cu_count = 0;
+    if (cu_count == 0) {
+        int dev = 0, n = 0;
+        ASR_HIP_CHECK(hipGetDevice(&dev));
+        ASR_HIP_CHECK(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev));
+        cu_count = n > 0 ? n / 8 * 8 : 8;                      // a multiple of 8: a workgroup's tiles stay on its XCD
+    }
+    if (!residual && a.Kpad / BK >= 4 && nwg > cu_count) {
+        auto kern = pw_gemm_f16x3_pre_ring_persist_kernel;
+        static AsrDeviceOnce once;
+        ASR_HIP_CHECK(asr_allow_dynamic_lds(once, reinterpret_cast<const void*>(kern), (int)lds));
+        hipLaunchKernelGGL(kern, dim3((unsigned)cu_count), dim3(768), lds, asr_stream(stream), a, (int)nwg);
+        ASR_LAUNCH_CHECK();
+        return ASR_OK;
+    }
     auto kern = pw_gemm_f16x3_pre_ring_kernel;
     static AsrDeviceOnce once;
     ASR_HIP_CHECK(asr_allow_dynamic_lds(once, reinterpret_cast<const void*>(kern), (int)lds));
