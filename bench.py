@@ -459,7 +459,7 @@ def rooflines(prof, provenance):
 
     if "pw16" in prof:
         out["roofline"] = gemm_roofline(
-            "pw16", "pw_gemm_f16x3_pre_ring_kernel / pw_gemm_f16x3_kernel (asr_pwconv_mfma_f16x3[_presplit], "
+            "pw16", "pw_gemm_f16x3_pre_ring[_persist]_kernel / pw_gemm_f16x3_kernel (asr_pwconv_mfma_f16x3[_presplit], "
                     "v_mfma_f32_16x16x32_f16 x3 / v_mfma_f32_32x32x16_f16 x3)",
             "pw_gemm_f16x3", round(F16_MFMA_PEAK_TFLOPS / 3.0, 1),
             "dense f16 MFMA peak 2500 TFLOP/s / 3 MFMA products per f32-grade product")
