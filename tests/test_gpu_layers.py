@@ -341,6 +341,46 @@ def test_presplit_sepconv_matches_the_f32_handoff(dev, c, n, hw, stride, rate):
     assert float(rec[:, c:].abs().max()) == 0.0 if chunks * 32 > c else True
 
 
+@pytest.mark.parametrize("k,n,relu", [(728, 728, 0), (256, 256, 1), (128, 256, 2), (1024, 1536, 1)])
+def test_presplit_gemm_persistent_walk_is_bit_identical_to_one_tile_per_workgroup(dev, k, n, relu):
+    """Without a residual and with more tiles than CUs asr_pwconv_mfma_f16x3_presplit walks the tiles with one persistent
+    workgroup per CU (the next tile's operands land under the current epilogue, the LDS ring runs on across the tile
+    boundary); otherwise one workgroup takes one tile.  Rows are independent, so the persistent launch over all rows must
+    equal, bit for bit, launches over row blocks small enough (<= 256 tiles) to take the one-tile kernel -- ragged M, the
+    padded last N-tile of 728, every activation mode, several tiles per workgroup -- and both sit within the f32-grade
+    bound of the float64 product."""
+    from asr_amd import ops
+    rng = np.random.default_rng(77)
+    m = 70000 + 37                                             # 274 row tiles, the last one ragged
+    chunks = (k + 31) // 32
+    a_h = _rand(rng, m, k)
+    hi = a_h.astype(np.float16)
+    lo = (a_h - hi.astype(np.float32)).astype(np.float16)
+    lines = np.zeros((m, chunks, 2, 32), np.float16)
+    pad = chunks * 32 - k
+    lines[:, :, 0, :] = np.pad(hi, ((0, 0), (0, pad))).reshape(m, chunks, 32)
+    lines[:, :, 1, :] = np.pad(lo, ((0, 0), (0, pad))).reshape(m, chunks, 32)
+    xs = torch.from_numpy(lines.reshape(m, chunks * 64)).to(dev).view(torch.float32).reshape(m, chunks, 32)
+    wk_h = _rand(rng, k, n, scale=(1.0 / k) ** 0.5)
+    bk_h = _rand(rng, n, scale=0.1)
+    w16 = ops.pack_pw_weights_f16x3(ops.to_device(wk_h))
+    bk = ops.to_device(bk_h)
+    tiles_n = -(-n // 256)
+    assert -(-m // 256) * tiles_n > 256                        # the whole launch: persistent
+    whole = ops.pwconv_presplit(xs, w16, bk, k, n, chunks, relu=relu)
+    rows = (256 // tiles_n) * 256                              # row blocks of <= 256 tiles: one tile per workgroup
+    parts = [ops.pwconv_presplit(xs[r0:r0 + rows].contiguous(), w16, bk, k, n, chunks, relu=relu) for r0 in range(0, m, rows)]
+    assert torch.equal(whole.view(torch.int32), torch.cat(parts).view(torch.int32))
+    a64 = (hi.astype(np.float64) + lo.astype(np.float64))
+    exact = a64 @ wk_h.astype(np.float64) + bk_h
+    if relu:
+        exact = np.maximum(exact, 0)
+    if relu == 2:
+        exact = np.minimum(exact, 6)
+    bound = np.abs(a64) @ np.abs(wk_h).astype(np.float64) + np.abs(bk_h)
+    assert (np.abs(whole.cpu().numpy()[:, :n] - exact) / bound).max() <= 4e-6
+
+
 @pytest.mark.parametrize("hw", [32, 64])
 def test_aspp_split_operands_match_the_f32_outputs(dev, hw):
     """asr_aspp_dwconv3_nhwc_split_f16 at the product shapes (32 x 32 x 2048 for 512 x 512 inputs, 64 x 64 x 2048 for the
