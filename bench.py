@@ -465,7 +465,7 @@ def rooflines(prof, provenance):
             "dense f16 MFMA peak 2500 TFLOP/s / 3 MFMA products per f32-grade product")
         if "pw" in prof:
             out["roofline_f32_mfma_layers"] = gemm_roofline(
-                "pw", "pw_gemm_kernel (layers with <= 64 output channels)", "pw_gemm_kernel<2, 2, 2, 1,",
+                "pw", "pw_gemm_kernel (layers with <= 32 output channels: the logits)", "pw_gemm_kernel<",
                 F32_MFMA_PEAK_TFLOPS, "FP32 MFMA peak (spec)")
     elif "pw" in prof:
         out["roofline"] = gemm_roofline("pw", "pw_gemm_kernel (asr_pwconv_mfma_f32, v_mfma_f32_32x32x2_f32)",
