@@ -1052,7 +1052,8 @@ static int launch_f16x3_shape(PwArgs& a, long long& nwg, asr_stream_t stream) {
 
 static int launch_f16x3(PwArgs a, int conv, asr_stream_t stream) {
     long long nwg = 0;
-    const int rc = conv == 0 ? launch_f16x3_shape<2, 2, 2, 2, false>(a, nwg, stream)
+    const int rc = conv == 0 ? (a.N <= 64 ? launch_f16x3_shape<2, 2, 2, 1, false>(a, nwg, stream)     // 128 x 64 tile
+                                          : launch_f16x3_shape<2, 2, 2, 2, false>(a, nwg, stream))
                  : conv == 1 ? launch_f16x3_shape<2, 2, 2, 2, true>(a, nwg, stream)
                              : launch_f16x3_shape<2, 2, 2, 1, true>(a, nwg, stream);
     if (rc != ASR_OK) return rc;
