@@ -151,7 +151,7 @@ class DeeplabEngine:
         kd = self._dev(k)
         conv = name == "entry_flow_conv1_2"                       # the one dense 3x3 on the matrix path (implicit GEMM)
         # <= 32 output channels (the logits) stay on the exact-f32 kernel: HBM-bound there and faster (401 against 510 us at
-        # 21 channels); from 33 up the split-f16 kernel wins even on its 64-wide tile (feature_projection0, 48: 630 -> 489 us)
+        # 21 channels); from 33 up the split-f16 kernel wins on its 128 x 64 tile (feature_projection0, 48 channels: 630 -> 417 us)
         split = pack and self.precision == "f16x3" and (k.shape[1] > 32 or conv)
         if split and name not in self.routed_f32:
             # range guard of the split-f16 arithmetic, weight side (hi = f16(w) must be finite and carry bits): a folded
