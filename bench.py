@@ -480,6 +480,11 @@ def rooflines(prof, provenance):
                 "algorithmic_bytes_per_launch": round(by / launches), "bytes_note": note,
                 "launches": launches, "avg_launch_ms": round(ms / launches, 4)}
 
+    if "pw16s" in prof:
+        out["roofline_small_n_layers"] = hbm_roofline(
+            "pw16s", "pw_gemm_f16x3_kernel<2, 2, 2, 1> (asr_pwconv_mfma_f16x3 with <= 64 output channels: feature_projection0; "
+                     "128 x 64 tile)", "pw_gemm_f16x3_kernel<2, 2, 2, 1,",
+            "layer input + layer output + weights (these layers are HBM-bound: 256 -> 48 channels reads 5.3x what it writes)")
     if "dw" in prof:
         out["roofline_depthwise"] = hbm_roofline(
             "dw", "dw_stream_full_kernel / aspp_dw3_phase_kernel (asr_dwconv3x3_nhwc_[split_]f32, asr_aspp_dwconv3_nhwc_*)",

@@ -267,7 +267,9 @@ class DeeplabEngine:
                 (x.ptr, p["w"].data_ptr(), p["b"].data_ptr() if p["b"] is not None else None,
                  res.ptr if res is not None else None, out.ptr + 4 * out_off, m, p["k"], p["n"], x.ld, ldy,
                  res.ld if res is not None else 0, int(relu), sub, h if sub > 1 else 0, w if sub > 1 else 0),
-                "pw16" if p.get("fn", "").endswith("f16x3") else "pw", 2.0 * m * p["k"] * p["n"],
+                # kind: split-f16 GEMMs are "pw16"; the <= 64-channel ones ("pw16s": the 128 x 64 tile, HBM-bound) and the
+                # exact-f32 ones ("pw") are booked apart, so that bench.py prices each family against its own bound
+                ("pw16" if p["n"] > 64 else "pw16s") if p.get("fn", "").endswith("f16x3") else "pw", 2.0 * m * p["k"] * p["n"],
                 4.0 * (m * p["k"] + m * p["n"] * (2 if res is not None else 1) + p["k"] * p["n"]),
                 label=f"{name} M={m} K={p['k']} N={p['n']}", out=out)
             return out

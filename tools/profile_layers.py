@@ -42,7 +42,7 @@ def main():
         print(f"  {k:5s} {m:8.2f} ms  {f / m / 1e9 if m else 0:8.1f} TF/s  {b / m / 1e6 if m else 0:8.1f} GB/s")
     shapes = {}
     for k, l, m, f, b in best:
-        if k in ("pw", "pw16", "dw"):
+        if k in ("pw", "pw16", "pw16s", "dw"):
             key = k + " " + " ".join(l.split()[1:])
             g = shapes.setdefault(key, [0, 0.0, 0.0, 0.0])
             g[0] += 1; g[1] += m; g[2] += f; g[3] += b
