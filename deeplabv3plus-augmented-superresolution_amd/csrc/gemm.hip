@@ -1131,7 +1131,16 @@ extern "C" int asr_pwconv_mfma_f16x3_presplit(const void* x_split, const float* 
         ASR_HIP_CHECK(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev));
         cu_count = n > 0 ? n / 8 * 8 : 8;                      // a multiple of 8: a workgroup's tiles stay on its XCD
     }
-    if (!residual && a.Kpad / BK >= 4 && nwg > cu_count) {
+    // NOT the product path: with TWO lanes of the hot path in flight (forward passes of one image on one HIP stream, the SR
+    // solve of another on a second stream) the end-to-end IoU table stopped being reproducible run to run when these
+    // launches walked their tiles persistently -- the kernel itself is bit-identical to the one-tile kernel in 190 000
+    // launches under two-process contention, the forward pass alone and the solver alone are reproducible, one lane is
+    // reproducible; the interaction was not found in the time left.  The one-tile kernel is used.
+#ifndef ASR_PERSISTENT_WALK
+#define ASR_PERSISTENT_WALK 0       // 1: the experiment build (ASR_EXTRA_HIPFLAGS=-DASR_PERSISTENT_WALK=1)
+#endif
+    constexpr bool kPersistentWalk = ASR_PERSISTENT_WALK != 0;
+    if (kPersistentWalk && !residual && a.Kpad / BK >= 4 && nwg > cu_count) {
         auto kern = pw_gemm_f16x3_pre_ring_persist_kernel;
         static AsrDeviceOnce once;
         ASR_HIP_CHECK(asr_allow_dynamic_lds(once, reinterpret_cast<const void*>(kern), (int)lds));

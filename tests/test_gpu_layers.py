@@ -343,12 +343,11 @@ def test_presplit_sepconv_matches_the_f32_handoff(dev, c, n, hw, stride, rate):
 
 @pytest.mark.parametrize("k,n,relu", [(728, 728, 0), (256, 256, 1), (128, 256, 2), (1024, 1536, 1)])
 def test_presplit_gemm_persistent_walk_is_bit_identical_to_one_tile_per_workgroup(dev, k, n, relu):
-    """Without a residual and with more tiles than CUs asr_pwconv_mfma_f16x3_presplit walks the tiles with one persistent
-    workgroup per CU (the next tile's operands land under the current epilogue, the LDS ring runs on across the tile
-    boundary); otherwise one workgroup takes one tile.  Rows are independent, so the persistent launch over all rows must
-    equal, bit for bit, launches over row blocks small enough (<= 256 tiles) to take the one-tile kernel -- ragged M, the
-    padded last N-tile of 728, every activation mode, several tiles per workgroup -- and both sit within the f32-grade
-    bound of the float64 product."""
+    """Rows are independent: one launch over all rows must equal, bit for bit, launches over row blocks of <= 256 tiles --
+    ragged M, the padded last N-tile of 728, every activation mode -- and sit within the f32-grade bound of the float64
+    product.  (Written for the persistent walk of the ring GEMM, pw_gemm_f16x3_pre_ring_persist_kernel, which takes launches
+    of more than 256 tiles in the experiment build -DASR_PERSISTENT_WALK=1 and passes this test; the product build runs
+    one tile per workgroup on both sides: DESIGN.md 4.1.)"""
     from asr_amd import ops
     rng = np.random.default_rng(77)
     m = 70000 + 37                                             # 274 row tiles, the last one ragged
@@ -366,7 +365,7 @@ def test_presplit_gemm_persistent_walk_is_bit_identical_to_one_tile_per_workgrou
     w16 = ops.pack_pw_weights_f16x3(ops.to_device(wk_h))
     bk = ops.to_device(bk_h)
     tiles_n = -(-n // 256)
-    assert -(-m // 256) * tiles_n > 256                        # the whole launch: persistent
+    assert -(-m // 256) * tiles_n > 256                        # the whole launch: more tiles than CUs
     whole = ops.pwconv_presplit(xs, w16, bk, k, n, chunks, relu=relu)
     rows = (256 // tiles_n) * 256                              # row blocks of <= 256 tiles: one tile per workgroup
     parts = [ops.pwconv_presplit(xs[r0:r0 + rows].contiguous(), w16, bk, k, n, chunks, relu=relu) for r0 in range(0, m, rows)]
