@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Reproducibility under stream concurrency: forward passes (100 copies, 512 x 512) on one HIP stream, SR solves on a second,
-each compared bit for bit with its first result.  Both must stay at 0 mismatches.  With the persistent walk of the ring GEMM
-compiled in (ASR_EXTRA_HIPFLAGS=-DASR_PERSISTENT_WALK=1 python <pkg>/csrc/build.py, library given with ASR_LIB=) the forward
-passes stay identical and ~15 % of the SOLVES differ (round 3): that build is not the product.
+each compared bit for bit with its first result.  Round 3 ("a known issue"): the forward passes stay identical,
+~15 % of the SOLVES differ -- with the product library and with the persistent-walk build alike; a solve that overlaps
+entry_stem_fused_kernel / sepconv_fused_kernel on the other stream is the one that moves.  The product pipeline's own timing
+(bench.py, two lanes) is reproducible; this tool is the reproducer for whoever finds the mechanism.
 
     python tools/stress_forward_vs_sr_streams.py
 """
