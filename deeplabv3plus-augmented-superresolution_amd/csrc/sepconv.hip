@@ -45,7 +45,6 @@ __global__ __launch_bounds__(512) void sepconv_fused_kernel(const float* __restr
                                                             const float* __restrict__ bp, float* __restrict__ y, int batch, int h,
                                                             int w, int ldx, int ldy, int npad, int pre_relu, int dw_relu,
                                                             int out_relu) {
-    asr_enable_f16_saturation();                              // the stage-1 split converts with the hardware's f16 clamp
     constexpr int QUADS = CIN / 4;                            // channel quads: 32 or 16
     constexpr int HALVES = 32 / QUADS;                        // row halves of the tile handled by different thread slots
     constexpr int RPT = SF_TH / HALVES;                       // output rows per thread: 8 or 4
@@ -136,8 +135,16 @@ __global__ __launch_bounds__(512) void sepconv_fused_kernel(const float* __restr
 #pragma unroll
                     for (int i = 0; i < 4; ++i) acc[i] = fmaxf(acc[i], 0.f);
                 }
-                unsigned int h01, h23, l01, l23;                // the split with saturating packed conversions (asr_common.h)
-                asr_split4_f16_saturating_mode(acc[0], acc[1], acc[2], acc[3], h01, h23, l01, l23);
+                // (the packed saturating split of asr_common.h is 2.4 - 3 % faster here, but with it this kernel joins
+                // entry_stem_fused_kernel in disturbing SR solves that run on another stream at the same time: DESIGN.md 4.1)
+                f16x4 hi, lo;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    _Float16 hf, lf;
+                    asr_split_f16(acc[i], hf, lf);
+                    hi[i] = hf;
+                    lo[i] = lf;
+                }
                 // Lanes 16 apart hold neighbouring channel quads (q even / odd) of the same pixel: they trade halves
                 // (v_permlane16_swap: row r of 16 lanes <-> row r ^ 1) so that the even quad's lane holds the 8 hi halfs of
                 // both quads and the odd quad's lane their 8 lo halfs -- ONE 16-byte LDS store per lane into a whole
@@ -145,7 +152,7 @@ __global__ __launch_bounds__(512) void sepconv_fused_kernel(const float* __restr
                 // hit each bank pair twice (20 % of the LDS cycles were bank conflicts, profiles/r02_pmc_sq.json).  Same
                 // bytes at the same LDS addresses as before.
                 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-                u32x2 h2 = {h01, h23}, l2 = {l01, l23};
+                u32x2 h2 = __builtin_bit_cast(u32x2, hi), l2 = __builtin_bit_cast(u32x2, lo);
                 {   // swap(a = hi, b = lo): a's odd rows <-> b's even rows
                     const auto sx = __builtin_amdgcn_permlane16_swap(h2.x, l2.x, false, false);
                     const auto sy = __builtin_amdgcn_permlane16_swap(h2.y, l2.y, false, false);
