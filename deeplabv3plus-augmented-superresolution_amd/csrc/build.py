@@ -22,12 +22,23 @@ VARIANTS = {"phase": ["-DASR_GEMM_PHASE_PROFILE"],      # s_memtime stamps per p
 # translation units that exist in one variant only (never in the product library)
 VARIANT_SOURCES = {"diag": [(os.path.join("diag", "gemm_diag.hip"), [])]}
 
+# No packed-f32 instructions (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32) in the kernels that run on the second lane next to
+# a forward pass.  Measured on MI355X (tools/diag_sr_stages_under_stem.py): with entry_stem_fused_kernel
+# resident on the same SIMD, K_fwd of the SR solver returned garbage in lanes 48-63 of ~0.5 % of its waves -- 12 of 12
+# solves, whatever the form of its loads -- and 0 of 12 when sr.hip is compiled without them (the compiler had paired the
+# coordinate arithmetic into packed ops that take the transform coefficients as SGPR pairs; these three files are the only
+# ones whose packed-f32 ops have scalar operands).  Same IEEE operations unpacked: results are bit-identical.
+# The flag reaches the host pass too, which prints "not a recognized feature for this target (ignoring feature)":
+# _compile() drops that line.
+NO_PK_F32 = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
+_HOST_NOISE = "'-packed-fp32-ops' is not a recognized feature for this target"
+
 # (source, extra flags)
 SOURCES = [
     ("core.cpp", []),
-    ("warp.hip", ["-ffp-contract=off"]),
-    ("sr.hip", ["-ffp-contract=off"]),
-    ("reduce.hip", ["-ffp-contract=off"]),
+    ("warp.hip", ["-ffp-contract=off"] + NO_PK_F32),
+    ("sr.hip", ["-ffp-contract=off"] + NO_PK_F32),
+    ("reduce.hip", ["-ffp-contract=off"] + NO_PK_F32),
     ("gemm.hip", ["-Wno-inline-asm"]),     # glds16_sbase names m0 as clobbered (it is: the LDS-DMA destination); clang flags any reserved register
     ("dwconv.hip", []),
     ("layers.hip", []),
@@ -43,6 +54,15 @@ def _hipcc():
         if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
             return c
     raise RuntimeError("hipcc not found")
+
+
+def _compile(cmd):
+    r = subprocess.run(cmd, stderr=subprocess.PIPE, text=True)
+    err = "\n".join(l for l in r.stderr.splitlines() if _HOST_NOISE not in l)
+    if err:
+        print(err, file=sys.stderr, flush=True)
+    if r.returncode:
+        raise subprocess.CalledProcessError(r.returncode, cmd)
 
 
 def _stale(target, deps):
@@ -88,7 +108,7 @@ def _build_locked(objdir, force, verbose, variant=""):
             cmd = [hipcc] + COMMON + extra + extra_all + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd), flush=True)
-            subprocess.check_call(cmd)
+            _compile(cmd)
     if force or _stale(lib, objs):
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs
         if verbose:
