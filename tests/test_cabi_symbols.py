@@ -66,3 +66,19 @@ def test_product_refuses_cpu_tensors(lib):
     from asr_amd import ops, _lib
     with pytest.raises(_lib.AsrError):
         ops.minmax(torch.zeros(16))
+
+
+def test_second_lane_kernels_are_built_without_packed_f32():
+    """csrc/build.py: sr / warp / reduce run next to forward passes on the second lane and are compiled without v_pk_*_f32
+    (K_fwd returned garbage lanes next to the fused stem kernel with them: DESIGN.md 4.1)."""
+    import importlib.util, os
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location(
+        "asr_build", os.path.join(here, "deeplabv3plus-augmented-superresolution_amd", "csrc", "build.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    flags = dict(b.SOURCES)
+    for src in ("sr.hip", "warp.hip", "reduce.hip"):
+        assert "-packed-fp32-ops" in flags[src] and "-ffp-contract=off" in flags[src], src
+    for src in ("gemm.hip", "dwconv.hip", "layers.hip", "sepconv.hip"):
+        assert "-packed-fp32-ops" not in flags[src], src

@@ -124,3 +124,61 @@ def test_opm_threshold_iou_properties_full_size(dev):
     a, b = (t1 == 8).cpu().numpy(), (other == 8).cpu().numpy()
     ref = (a & b).sum() / (a | b).sum()
     assert compute_IoU(t1, other, img_size=(H, W), class_id=8) == ref == compute_IoU(other, t1, img_size=(H, W), class_id=8)
+
+
+def test_sr_solve_next_to_the_fused_stem_on_another_stream(dev):
+    """An SR iteration that runs while entry_stem_fused_kernel occupies the chip on ANOTHER stream returns the values of
+    a quiet run, stage by stage (residuals, gradient planes, x).  Round 3 found K_fwd returning garbage in lanes 48-63 of
+    a few waves here (12 of 12 trials) while sr.hip was compiled with packed-f32 instructions; csrc/build.py compiles the
+    second-lane kernels without them (tools/diag_sr_stages_under_stem.py is the long form of this test)."""
+    from asr_amd import _lib, ops, transforms as T, weights as Wt
+    from asr_amd.model import DeeplabModel
+    model = DeeplabModel(Wt.make_synthetic_weights(1234), (H, W, 3), 21, False, None)
+    g = torch.Generator(device="cpu").manual_seed(5)
+    xin = torch.rand((N, H, W, 3), generator=g).to(dev)
+    model.engine.forward(xin, lane=0)
+    torch.cuda.synchronize()
+    plan = model.engine.plan(N, H, W, 0)
+    stem = [(name, args) for name, args, kind, *_ in plan["steps"] if kind == "conv"]
+    assert stem and stem[0][0] == "asr_entry_stem_f16x3"
+    lib = _lib.load()
+
+    rng = np.random.RandomState(3)
+    y = ops.to_device((rng.rand(1, N, h, w) > 0.6).astype(np.float32))
+    angles = rng.uniform(-0.15, 0.15, N).astype(np.float32)
+    shifts = rng.uniform(-80, 80, (N, 2)).astype(np.float32)
+    tf = lambda a: ops.to_device(a.reshape(1, N, 8))
+    rot, irot = tf(T.rotation_transforms(angles, H, W)), tf(T.rotation_transforms(-angles, H, W))
+    tr, itr = tf(T.translation_transforms(shifts)), tf(T.translation_transforms(-shifts))
+    b1, b2 = np.float32(0.9), np.float32(0.999)
+    alphas = ops.to_device(np.array([[T.adam_alpha(np.float32(1e-3), b1, b2, 1)]], np.float32))
+    cfg = ops.sr_config(_lib.OPT_ADAM, True, np.float32(1) - b1, np.float32(1) - b2, np.float32(1e-7))
+
+    def one_iteration():
+        st = {}
+        x0 = ops.sr_init_target(y, (H, W))
+        ops.sr_solve(x0, y, rot, tr, irot, itr, alphas, (1.0, 0.3, 0.7, 0.0), want_loss=False, cfg=cfg, state=st)
+        return x0, st["ws"]
+
+    def stages(x, ws):      # sr.hip, asr_sr_solve_cfg_f32: resid | x_alt | acc | planes | bordered x | flags
+        pe = (H + 4) * (W + 64)
+        o = N * h * w + 2 * H * W
+        chunk = (ws.numel() - 1 - o - pe) // pe
+        return ws[:N * h * w], ws[o:o + chunk * pe], x
+
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    with torch.cuda.stream(sb):
+        xq, wsq = one_iteration()
+    torch.cuda.synchronize()
+    quiet = [t.clone() for t in stages(xq, wsq)]
+    for trial in range(6):
+        with torch.cuda.stream(sa):
+            s = _lib.stream_ptr()
+            for _ in range(6):
+                for name, args in stem:
+                    assert getattr(lib, name)(*args, s) == 0
+        with torch.cuda.stream(sb):
+            xt, wst = one_iteration()
+        torch.cuda.synchronize()
+        for what, got, ref in zip(("residuals", "gradient planes", "x"), stages(xt, wst), quiet):
+            assert torch.equal(got, ref), f"trial {trial}: {what} differ in {int((got != ref).sum())} elements"

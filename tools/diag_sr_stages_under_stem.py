@@ -4,7 +4,12 @@ A ONE-iteration solve writes every intermediate into the caller's workspace -- r
 bordered copy of the new x and x itself (K_bwd) -- so a quiet solve and solves overlapped with replays of the stem launch
 can be compared stage by stage, bit for bit.
 
-    python tools/diag_sr_stages_under_stem.py [trials]
+    python tools/diag_sr_stages_under_stem.py [trials] [all]     # "all": + the sentinel and prefilled-workspace phases
+    ASR_LIB=<variant library> python tools/diag_sr_stages_under_stem.py 12     # a variant of sr.hip linked against the product objects
+
+Round 3 (profiles/r03_sr_next_to_stem_diagnosis.txt): with packed-f32 instructions in sr.hip the residuals of K_fwd were
+garbage in lanes 48-63 of ~130 of its 25 600 waves, 44 of 44 trials, whatever the form of the loads; without them 0 of 32.
+csrc/build.py builds sr.hip / warp.hip / reduce.hip without them; this tool now reports "0 of N moved".
 """
 import sys
 import numpy as np, torch

@@ -1,9 +1,8 @@
 #!/usr/bin/env python3
 """Reproducibility under stream concurrency: forward passes (100 copies, 512 x 512) on one HIP stream, SR solves on a second,
-each compared bit for bit with its first result.  Round 3 ("a known issue"): the forward passes stay identical,
-~15 % of the SOLVES differ -- with the product library and with the persistent-walk build alike; a solve that overlaps
-entry_stem_fused_kernel / sepconv_fused_kernel on the other stream is the one that moves.  The product pipeline's own timing
-(bench.py, two lanes) is reproducible; this tool is the reproducer for whoever finds the mechanism.
+each compared bit for bit with its first result.  Round 3: the forward passes always stayed identical; 15-20 %
+of the SOLVES differed while sr.hip was compiled with packed-f32 instructions (K_fwd next to entry_stem_fused_kernel:
+tools/diag_sr_stages_under_stem.py), 0 of 382 x 8 since csrc/build.py compiles the second-lane kernels without them.
 
     python tools/stress_forward_vs_sr_streams.py
 """
