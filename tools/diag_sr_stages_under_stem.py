@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Which stage of an SR iteration moves when entry_stem_fused_kernel runs on another stream ("a known issue")?
+"""Which stage of an SR iteration moves when entry_stem_fused_kernel runs on another stream?
 A ONE-iteration solve writes every intermediate into the caller's workspace -- resid (K_fwd), the G_R planes (K_gt), the
 bordered copy of the new x and x itself (K_bwd) -- so a quiet solve and solves overlapped with replays of the stem launch
 can be compared stage by stage, bit for bit.
