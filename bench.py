@@ -287,8 +287,9 @@ def profile_provenance():
     import hashlib
     csrc = os.path.join(ROOT, "deeplabv3plus-augmented-superresolution_amd", "csrc")
     h = hashlib.sha256()
+    # build.py is hashed too: its per-file flags (e.g. no packed-f32 in sr / warp / reduce) decide the code objects
     for f in sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h")) +
-                    glob.glob(os.path.join(csrc, "*.cpp"))):
+                    glob.glob(os.path.join(csrc, "*.cpp")) + [os.path.join(csrc, "build.py")]):
         h.update(os.path.basename(f).encode())
         with open(f, "rb") as fh:
             h.update(fh.read())

@@ -23,7 +23,7 @@ python3 - "$commit" > $out/csrc.sha256 <<'PY'
 import glob, hashlib, os, sys
 csrc = os.path.join("deeplabv3plus-augmented-superresolution_amd", "csrc")
 h = hashlib.sha256()
-for f in sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h")) + glob.glob(os.path.join(csrc, "*.cpp"))):
+for f in sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h")) + glob.glob(os.path.join(csrc, "*.cpp")) + [os.path.join(csrc, "build.py")]):
     h.update(os.path.basename(f).encode())
     h.update(open(f, "rb").read())
 print(h.hexdigest(), sys.argv[1])
