@@ -67,6 +67,21 @@ static inline int64_t asr_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 // ---- device helpers -------------------------------------------------------------------
 #ifdef __HIPCC__
 
+// Packed-f32 instructions (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32) are OFF for every translation unit of the library
+// (csrc/build.py: NO_PK_F32) and switched back on, kernel by kernel, with this attribute.  Measured on MI355X (DESIGN.md 4.1,
+// profiles/r04_hazard_matrix.txt): a wave that executes them returns garbage in lanes 48-63 of some of them while it shares
+// a SIMD with two waves of entry_stem_fused_kernel / sepconv_fused_kernel (another stream); the same kernel without them
+// never does, and a kernel too large to fit beside those waves is never in that position.  So only kernels that allocate
+// MORE than 112 vector registers (512 - 2 x 200) may carry the attribute; csrc/isa_guard.py checks the machine code for
+// exactly that after every link.  Same IEEE operations packed or not: results are bit-identical either way.
+// (An opt-IN, because the inliner only merges a callee whose target features are a subset of its caller's: helpers and
+// lambdas compiled without the feature inline into a kernel that has it, not the other way round.)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define ASR_PK_F32 __attribute__((target("packed-fp32-ops")))
+#else
+#define ASR_PK_F32                                             // (the host pass of hipcc does not know the gfx950 feature)
+#endif
+
 // One flat projective transform (ImageProjectiveTransformV3 parameter vector).
 struct AsrTf8 {
     float a0, a1, a2, b0, b1, b2, c0, c1;
@@ -77,6 +92,11 @@ __device__ __forceinline__ AsrTf8 asr_load_tf(const float* __restrict__ t) {
     r.a0 = t[0]; r.a1 = t[1]; r.a2 = t[2];
     r.b0 = t[3]; r.b1 = t[4]; r.b2 = t[5];
     r.c0 = t[6]; r.c1 = t[7];
+#ifdef ASR_TF_IN_VGPR
+    // The coefficients are wave-uniform and arrive in SGPRs; pin copies in vector registers, so that whatever packed-f32
+    // arithmetic the compiler forms from them takes VECTOR operands only (packed-f32 with SGPR sources).
+    asm volatile("" : "+v"(r.a0), "+v"(r.a1), "+v"(r.a2), "+v"(r.b0), "+v"(r.b1), "+v"(r.b2), "+v"(r.c0), "+v"(r.c1));
+#endif
     return r;
 }
 
@@ -105,16 +125,32 @@ __device__ __forceinline__ void asr_split_f16(float v, _Float16& hi, _Float16& l
 // stays one (MODE.FP16_OVFL preserves INF), where asr_split_f16 gives 65504.
 typedef float asr_f32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 asr_f16x2 __attribute__((ext_vector_type(2)));
+// ASR_DIAG_TOUCH_VGPR(n): raise the kernel's vector-register allocation to n + 1 (diagnostic builds only: how many waves of
+// which kernels share a SIMD's 512 registers is one of the variables of tools/build_hazard_variants.py)
+#define ASR_DIAG_STR2(x) #x
+#define ASR_DIAG_STR(x) ASR_DIAG_STR2(x)
+#define ASR_DIAG_TOUCH_VGPR(n) asm volatile("v_mov_b32 v" ASR_DIAG_STR(n) ", 0" ::: "v" ASR_DIAG_STR(n))
+// Diagnostic switches (tools/build_hazard_variants.py; never defined in the product build): ASR_DIAG_NO_SETREG leaves MODE
+// alone (the packed conversions then overflow to infinity), ASR_DIAG_SCALAR_SPLIT keeps the MODE write but splits value by
+// value with clamps like asr_split_f16.
 __device__ __forceinline__ void asr_enable_f16_saturation() {
+#ifndef ASR_DIAG_NO_SETREG
     __builtin_amdgcn_s_setreg(1 | (23 << 6), 1);   // hwreg(HW_REG_MODE, 23, 1) = FP16_OVFL: an overflowing f16 result clamps to +-MAX
+#endif
 }
 // hi01, hi23, lo01, lo23: two halves per dword, element order preserved
 __device__ __forceinline__ void asr_split4_f16_saturating_mode(float v0, float v1, float v2, float v3, unsigned int& hi01,
                                                                unsigned int& hi23, unsigned int& lo01, unsigned int& lo23) {
+#ifdef ASR_DIAG_SCALAR_SPLIT
+    _Float16 h[4], l[4];
+    asr_split_f16(v0, h[0], l[0]); asr_split_f16(v1, h[1], l[1]); asr_split_f16(v2, h[2], l[2]); asr_split_f16(v3, h[3], l[3]);
+    const asr_f16x2 ha = {h[0], h[1]}, hb = {h[2], h[3]}, la = {l[0], l[1]}, lb = {l[2], l[3]};
+#else
     const asr_f32x2 a = {v0, v1}, b = {v2, v3};
     const asr_f16x2 ha = __builtin_convertvector(a, asr_f16x2), hb = __builtin_convertvector(b, asr_f16x2);
     const asr_f32x2 ra = a - __builtin_convertvector(ha, asr_f32x2), rb = b - __builtin_convertvector(hb, asr_f32x2);
     const asr_f16x2 la = __builtin_convertvector(ra, asr_f16x2), lb = __builtin_convertvector(rb, asr_f16x2);
+#endif
     hi01 = __builtin_bit_cast(unsigned int, ha); hi23 = __builtin_bit_cast(unsigned int, hb);
     lo01 = __builtin_bit_cast(unsigned int, la); lo23 = __builtin_bit_cast(unsigned int, lb);
 }

@@ -22,12 +22,13 @@ VARIANTS = {"phase": ["-DASR_GEMM_PHASE_PROFILE"],      # s_memtime stamps per p
 # translation units that exist in one variant only (never in the product library)
 VARIANT_SOURCES = {"diag": [(os.path.join("diag", "gemm_diag.hip"), [])]}
 
-# No packed-f32 instructions (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32) in the kernels that run on the second lane next to
-# a forward pass.  Measured on MI355X (tools/diag_sr_stages_under_stem.py): with entry_stem_fused_kernel
-# resident on the same SIMD, K_fwd of the SR solver returned garbage in lanes 48-63 of ~0.5 % of its waves -- 12 of 12
-# solves, whatever the form of its loads -- and 0 of 12 when sr.hip is compiled without them (the compiler had paired the
-# coordinate arithmetic into packed ops that take the transform coefficients as SGPR pairs; these three files are the only
-# ones whose packed-f32 ops have scalar operands).  Same IEEE operations unpacked: results are bit-identical.
+# No packed-f32 instructions (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32) by default, in every translation unit; the kernels
+# that may use them opt back in one by one (ASR_PK_F32 in asr_common.h).  Measured on MI355X (DESIGN.md 4.1,
+# tools/build_hazard_variants.py, profiles/r04_hazard_matrix.txt): a wave that executes them returned garbage in lanes 48-63
+# while it shared a SIMD with two waves of entry_stem_fused_kernel / sepconv_fused_kernel of another stream -- 12 of 12
+# one-iteration SR solves in every variant in which the solver's waves fit beside those (<= 112 registers), 0 of 12 when
+# they do not fit or contain no packed-f32 instruction.  Same IEEE operations unpacked: results are bit-identical.
+# isa_guard.py (run below, after the link) fails the build if a kernel of <= 112 registers contains one.
 # The flag reaches the host pass too, which prints "not a recognized feature for this target (ignoring feature)":
 # _compile() drops that line.
 NO_PK_F32 = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
@@ -39,10 +40,10 @@ SOURCES = [
     ("warp.hip", ["-ffp-contract=off"] + NO_PK_F32),
     ("sr.hip", ["-ffp-contract=off"] + NO_PK_F32),
     ("reduce.hip", ["-ffp-contract=off"] + NO_PK_F32),
-    ("gemm.hip", ["-Wno-inline-asm"]),     # glds16_sbase names m0 as clobbered (it is: the LDS-DMA destination); clang flags any reserved register
-    ("dwconv.hip", []),
-    ("layers.hip", []),
-    ("sepconv.hip", []),
+    ("gemm.hip", ["-Wno-inline-asm"] + NO_PK_F32),     # glds16_sbase names m0 as clobbered (it is: the LDS-DMA destination); clang flags any reserved register
+    ("dwconv.hip", NO_PK_F32),
+    ("layers.hip", NO_PK_F32),
+    ("sepconv.hip", NO_PK_F32),
 ]
 HEADERS = ["asr_common.h", "asr_warp_device.h", "gemm_common.h", os.path.join("..", "..", "include", "asr_hip.h")]
 COMMON = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
@@ -70,6 +71,20 @@ def _stale(target, deps):
         return True
     t = os.path.getmtime(target)
     return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _isa_guard(lib):
+    """csrc/isa_guard.py over the freshly linked library; [] when the LLVM tools are not installed (a warning, not a failure:
+    the check is also a CPU test)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("asr_isa_guard", os.path.join(HERE, "isa_guard.py"))
+    guard = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(guard)
+    try:
+        return guard.violations(lib)
+    except guard.ToolMissing as e:
+        print(f"build.py: isa_guard skipped ({e})", file=sys.stderr, flush=True)
+        return []
 
 
 def build(force=False, verbose=True):
@@ -109,13 +124,20 @@ def _build_locked(objdir, force, verbose, variant=""):
             if verbose:
                 print(" ".join(cmd), flush=True)
             _compile(cmd)
-    if force or _stale(lib, objs):
+    relinked = force or _stale(lib, objs)
+    if relinked:
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
     with open(stamp, "w") as fh:
         fh.write(flags_now)
+    if relinked and not variant:
+        bad = _isa_guard(lib)
+        if bad:
+            os.replace(lib, lib + ".rejected")                  # never leave a library behind that breaks the rules
+            raise RuntimeError("isa_guard: %d violation(s) in the product library, first: %s in %s (%s); kept as %s"
+                               % (len(bad), bad[0][1], bad[0][0], bad[0][2], lib + ".rejected"))
     return lib
 
 

@@ -144,7 +144,7 @@ constexpr bool kNtStores = ASR_DW_NT != 0;
 #define ASR_DW_SMALL_MAX 64
 #endif
 template <int R, int S, int SROWS, int PF, bool SPLIT, int ACT>
-__global__ __launch_bounds__(256) void dw_stream_full_kernel(DwArgs p, int tiles_x) {
+__global__ __launch_bounds__(256) ASR_PK_F32 void dw_stream_full_kernel(DwArgs p, int tiles_x) {
     constexpr int WIN = 2 * R + 1;
     static_assert(SROWS % PF == 0, "strip length must be a multiple of the prefetch depth");
     const int tid = threadIdx.x;

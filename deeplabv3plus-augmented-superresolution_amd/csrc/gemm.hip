@@ -413,7 +413,7 @@ __global__ __launch_bounds__(WM * WN * 64) void pw_gemm_f16x3_kernel(PwArgs p) {
 // tile ahead; scheduling barriers keep the compiler from hoisting every read, which would spill).  Same MFMA sequence
 // per accumulator as every earlier form => bit-identical results.
 // =================================================================================================
-__global__ __launch_bounds__(768, 3) void pw_gemm_f16x3_pre_ring_kernel(PwArgs p) {
+__global__ __launch_bounds__(768, 3) ASR_PK_F32 void pw_gemm_f16x3_pre_ring_kernel(PwArgs p) {
     constexpr int BM = 256, BN = 256, RT = 4, CT = 8;
     constexpr int UNIT = 32 * 1024, RING = 5, B_PLANE = 4 * BN * 16;      // B unit = hi plane (16 KB) + lo plane
     constexpr int PIECES = 8;                                  // 1 KiB pieces per loader wave and unit (4 loaders x 8 = 32 KB)
@@ -670,7 +670,7 @@ __global__ __launch_bounds__(768, 3) void pw_gemm_f16x3_pre_ring_kernel(PwArgs p
 // held only the bias row) and have landed long before its epilogue ends: no prologue (and no workgroup dispatch) between
 // tiles.  One barrier after the epilogue tells the loaders that the bias row is no longer read, then unit 2 of the next
 // tile takes its slot.  Same MFMA sequence per accumulator, same epilogue: bit-identical to the one-tile kernel.
-__global__ __launch_bounds__(768, 3) void pw_gemm_f16x3_pre_ring_persist_kernel(PwArgs p, int ntiles) {
+__global__ __launch_bounds__(768, 3) ASR_PK_F32 void pw_gemm_f16x3_pre_ring_persist_kernel(PwArgs p, int ntiles) {
     constexpr int BM = 256, BN = 256, RT = 4, CT = 8;
     constexpr int UNIT = 32 * 1024, RING = 5, B_PLANE = 4 * BN * 16;      // B unit = hi plane (16 KB) + lo plane
     constexpr int PIECES = 8;                                  // 1 KiB pieces per loader wave and unit (4 loaders x 8 = 32 KB)
@@ -1124,20 +1124,16 @@ extern "C" int asr_pwconv_mfma_f16x3_presplit(const void* x_split, const float* 
     constexpr size_t lds = 5 * 32 * 1024;                      // the five-unit ring: all of the CU's LDS
     // Without a residual (whose staging needs the ring's free slots in the epilogue) and with more tiles than CUs the
     // tiles are walked by one persistent workgroup per CU: the next tile's first units land under the current epilogue.
-    static int cu_count = 0;
-    if (cu_count == 0) {
-        int dev = 0, n = 0;
-        ASR_HIP_CHECK(hipGetDevice(&dev));
-        ASR_HIP_CHECK(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev));
-        cu_count = n > 0 ? n / 8 * 8 : 8;                      // a multiple of 8: a workgroup's tiles stay on its XCD
-    }
-    // NOT the product path: with TWO lanes of the hot path in flight (forward passes of one image on one HIP stream, the SR
-    // solve of another on a second stream) the end-to-end IoU table stopped being reproducible run to run when these
-    // launches walked their tiles persistently -- the kernel itself is bit-identical to the one-tile kernel in 190 000
-    // launches under two-process contention, the forward pass alone and the solver alone are reproducible, one lane is
-    // reproducible; the interaction was not found in the time left.  The one-tile kernel is used.
+    const int cus = asr_device_cu_count();
+    ASR_REQUIRE(cus > 0, "asr_pwconv_mfma_f16x3_presplit: no device");
+    const int cu_count = cus >= 8 ? cus / 8 * 8 : cus;        // a multiple of 8: a workgroup's tiles stay on its XCD
+    // The persistent walk is the product path since round 4.  Round 3 held it back because, with two lanes in flight, it moved
+    // the forward pass's kernels to where the other lane's SR solves met the fused entry-flow kernels on a SIMD -- an
+    // interaction of packed-f32 instructions in the SOLVER's kernels (csrc/isa_guard.py keeps them out of every
+    // kernel small enough to share a SIMD with those kernels).  This kernel itself was never part of it: bit-identical to
+    // the one-tile kernel (tests/test_gpu_layers.py), and its twelve waves leave no room for a co-resident wave.
 #ifndef ASR_PERSISTENT_WALK
-#define ASR_PERSISTENT_WALK 0       // 1: the experiment build (ASR_EXTRA_HIPFLAGS=-DASR_PERSISTENT_WALK=1)
+#define ASR_PERSISTENT_WALK 1       // 0: the one-tile kernel for every launch (A/B builds: ASR_EXTRA_HIPFLAGS=-DASR_PERSISTENT_WALK=0)
 #endif
     constexpr bool kPersistentWalk = ASR_PERSISTENT_WALK != 0;
     if (kPersistentWalk && !residual && a.Kpad / BK >= 4 && nwg > cu_count) {

@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256) void conv3x3_direct_kernel(const float* __rest
 // generic kernel at 1.0 TB/s) and hand them round with ds_bpermute; a weight quad read from LDS serves SP pixels.
 constexpr int SP = 4;
 
-__global__ __launch_bounds__(256) void conv3x3_stem_kernel(const float* __restrict__ x, const float* __restrict__ w,
+__global__ __launch_bounds__(256) ASR_PK_F32 void conv3x3_stem_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                            const float* __restrict__ bias, float* __restrict__ y, int batch,
                                                            int h_in, int w_in, int stride, int pad_top, int pad_left, int h_out,
                                                            int w_out, int ldx, int ldy, int relu) {
@@ -150,7 +150,7 @@ __device__ __forceinline__ void split16_f16(const float (&a)[16], f16x8 (&hi)[2]
 }
 
 
-__global__ __launch_bounds__(256) void conv3x3_stem_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w,
+__global__ __launch_bounds__(256) ASR_PK_F32 void conv3x3_stem_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                                 const float* __restrict__ bias, float* __restrict__ y, int batch,
                                                                 int h_in, int w_in, int stride, int pad_top, int pad_left,
                                                                 int h_out, int w_out, int ldx, int ldy, int relu) {
@@ -239,11 +239,14 @@ constexpr int ES_LS = 32;
 constexpr int ES_T1_BYTES = ES_H * ES_LS * 128, ES_B_BYTES = 36 * 64 * 16, ES_LDS_BYTES = ES_T1_BYTES + 2 * ES_B_BYTES;   // 144 KB
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
-__global__ __launch_bounds__(512) void entry_stem_fused_kernel(const float* __restrict__ x, const float* __restrict__ w1,
+__global__ __launch_bounds__(512) ASR_PK_F32 void entry_stem_fused_kernel(const float* __restrict__ x, const float* __restrict__ w1,
                                                                const float* __restrict__ b1, const _Float16* __restrict__ w2p,
                                                                const float* __restrict__ b2, float* __restrict__ y, int batch,
                                                                int h_in, int w_in, int h1, int w1d, int ldx, int ldy, int npad2) {
     asr_enable_f16_saturation();                              // the splits below convert with the hardware's f16 clamp
+#ifdef ASR_DIAG_STEM_TOP_VGPR
+    ASR_DIAG_TOUCH_VGPR(ASR_DIAG_STEM_TOP_VGPR);
+#endif
     extern __shared__ __attribute__((aligned(16))) char es_lds[];
     char* const T1 = es_lds;
     char* const Bh = es_lds + ES_T1_BYTES;

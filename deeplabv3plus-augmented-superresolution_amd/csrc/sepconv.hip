@@ -17,6 +17,14 @@
 // two-kernel form, so the results are bit-identical to asr_dwconv3x3_nhwc_f32 + asr_pwconv_mfma_f16x3.
 #include "asr_common.h"
 
+// 1: the stage-1 split uses the packed saturating conversions of asr_common.h (2.4 - 3 % faster than clamp + convert per
+// value).  Round 3 switched it off because with it (208 instead of 212 registers) a wave of the SR solver fits beside two of
+// this kernel's waves on a SIMD, and the solver's packed-f32 instructions then went wrong; since round 4 no
+// kernel small enough to fit there contains such instructions (csrc/isa_guard.py).
+#ifndef ASR_SEPCONV_PACKED_SPLIT
+#define ASR_SEPCONV_PACKED_SPLIT 1
+#endif
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
@@ -39,12 +47,23 @@ __device__ __forceinline__ f32x4 sf_dpp4(f32x4 v) {           // a DPP row shift
 
 __device__ __forceinline__ int sf_swz(int slot, int line) { return (slot & ~15) | ((slot ^ line) & 15); }
 
+#ifdef ASR_DIAG_SEPCONV_MAX_VGPR
+#define ASR_SEPCONV_ATTR __attribute__((amdgpu_num_vgpr(ASR_DIAG_SEPCONV_MAX_VGPR)))
+#else
+#define ASR_SEPCONV_ATTR
+#endif
 template <int CIN>
-__global__ __launch_bounds__(512) void sepconv_fused_kernel(const float* __restrict__ x, const float* __restrict__ wd,
+__global__ __launch_bounds__(512) ASR_PK_F32 ASR_SEPCONV_ATTR void sepconv_fused_kernel(const float* __restrict__ x, const float* __restrict__ wd,
                                                             const float* __restrict__ bd, const _Float16* __restrict__ wp,
                                                             const float* __restrict__ bp, float* __restrict__ y, int batch, int h,
                                                             int w, int ldx, int ldy, int npad, int pre_relu, int dw_relu,
                                                             int out_relu) {
+#if ASR_SEPCONV_PACKED_SPLIT
+    asr_enable_f16_saturation();                              // the stage-1 split converts with the hardware's f16 clamp
+#endif
+#ifdef ASR_DIAG_SEPCONV_TOP_VGPR
+    ASR_DIAG_TOUCH_VGPR(ASR_DIAG_SEPCONV_TOP_VGPR);
+#endif
     constexpr int QUADS = CIN / 4;                            // channel quads: 32 or 16
     constexpr int HALVES = 32 / QUADS;                        // row halves of the tile handled by different thread slots
     constexpr int RPT = SF_TH / HALVES;                       // output rows per thread: 8 or 4
@@ -135,8 +154,12 @@ __global__ __launch_bounds__(512) void sepconv_fused_kernel(const float* __restr
 #pragma unroll
                     for (int i = 0; i < 4; ++i) acc[i] = fmaxf(acc[i], 0.f);
                 }
-                // (the packed saturating split of asr_common.h is 2.4 - 3 % faster here, but with it this kernel joins
-                // entry_stem_fused_kernel in disturbing SR solves that run on another stream at the same time: DESIGN.md 4.1)
+                typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+#if ASR_SEPCONV_PACKED_SPLIT
+                unsigned int h01, h23, l01, l23;                // the split with saturating packed conversions (asr_common.h)
+                asr_split4_f16_saturating_mode(acc[0], acc[1], acc[2], acc[3], h01, h23, l01, l23);
+                u32x2 h2 = {h01, h23}, l2 = {l01, l23};
+#else
                 f16x4 hi, lo;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -145,14 +168,14 @@ __global__ __launch_bounds__(512) void sepconv_fused_kernel(const float* __restr
                     hi[i] = hf;
                     lo[i] = lf;
                 }
+                u32x2 h2 = __builtin_bit_cast(u32x2, hi), l2 = __builtin_bit_cast(u32x2, lo);
+#endif
                 // Lanes 16 apart hold neighbouring channel quads (q even / odd) of the same pixel: they trade halves
                 // (v_permlane16_swap: row r of 16 lanes <-> row r ^ 1) so that the even quad's lane holds the 8 hi halfs of
                 // both quads and the odd quad's lane their 8 lo halfs -- ONE 16-byte LDS store per lane into a whole
                 // swizzled slot (conflict-free: 8 consecutive lines per store phase) instead of two 8-byte stores that
                 // hit each bank pair twice (20 % of the LDS cycles were bank conflicts, profiles/r02_pmc_sq.json).  Same
                 // bytes at the same LDS addresses as before.
-                typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-                u32x2 h2 = __builtin_bit_cast(u32x2, hi), l2 = __builtin_bit_cast(u32x2, lo);
                 {   // swap(a = hi, b = lo): a's odd rows <-> b's even rows
                     const auto sx = __builtin_amdgcn_permlane16_swap(h2.x, l2.x, false, false);
                     const auto sy = __builtin_amdgcn_permlane16_swap(h2.y, l2.y, false, false);

@@ -85,10 +85,18 @@ __device__ __forceinline__ void sr_map_affine(const AsrTf8& t, float x, float y,
 
 // ---- K_fwd --------------------------------------------------------------------------------
 // One thread per LR residual element (b, n, i, j).  BORDERED: x is the solver's zero-bordered copy [batch, H+4, W+64].
+#ifdef ASR_DIAG_KFWD_MAX_VGPR
+#define ASR_KFWD_ATTR __attribute__((amdgpu_num_vgpr(ASR_DIAG_KFWD_MAX_VGPR)))
+#else
+#define ASR_KFWD_ATTR
+#endif
 template <bool BORDERED>
-__global__ __launch_bounds__(256) void sr_forward_residual_kernel(
+__global__ __launch_bounds__(256) ASR_KFWD_ATTR void sr_forward_residual_kernel(
     const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ rot_tf,
     const float* __restrict__ trans_tf, float* __restrict__ resid, SrDims d) {
+#ifdef ASR_DIAG_KFWD_TOP_VGPR
+    ASR_DIAG_TOUCH_VGPR(ASR_DIAG_KFWD_TOP_VGPR);
+#endif
     const int j = blockIdx.x * kTileX + threadIdx.x;
     const int i = blockIdx.y * kTileY + threadIdx.y;
     const int bn = blockIdx.z;  // b * n + copy

@@ -126,21 +126,39 @@ def test_opm_threshold_iou_properties_full_size(dev):
     assert compute_IoU(t1, other, img_size=(H, W), class_id=8) == ref == compute_IoU(other, t1, img_size=(H, W), class_id=8)
 
 
-def test_sr_solve_next_to_the_fused_stem_on_another_stream(dev):
-    """An SR iteration that runs while entry_stem_fused_kernel occupies the chip on ANOTHER stream returns the values of
-    a quiet run, stage by stage (residuals, gradient planes, x).  Round 3 found K_fwd returning garbage in lanes 48-63 of
-    a few waves here (12 of 12 trials) while sr.hip was compiled with packed-f32 instructions; csrc/build.py compiles the
-    second-lane kernels without them (tools/diag_sr_stages_under_stem.py is the long form of this test)."""
-    from asr_amd import _lib, ops, transforms as T, weights as Wt
-    from asr_amd.model import DeeplabModel
-    model = DeeplabModel(Wt.make_synthetic_weights(1234), (H, W, 3), 21, False, None)
+def _fused_entry_launches(model, dev):
+    """The launches of a 100-copy forward pass that keep two >= 200-register waves on every SIMD: the fused stem and the two
+    fused separable convs of entry-flow block 1 (name, args) -- the kernels beside which round 3's SR solves went wrong."""
     g = torch.Generator(device="cpu").manual_seed(5)
     xin = torch.rand((N, H, W, 3), generator=g).to(dev)
     model.engine.forward(xin, lane=0)
     torch.cuda.synchronize()
     plan = model.engine.plan(N, H, W, 0)
-    stem = [(name, args) for name, args, kind, *_ in plan["steps"] if kind == "conv"]
-    assert stem and stem[0][0] == "asr_entry_stem_f16x3"
+    fused = [(name, args) for name, args, *_ in plan["steps"] if name in ("asr_entry_stem_f16x3", "asr_sepconv_fused_f16x3")]
+    assert [n for n, _ in fused] == ["asr_entry_stem_f16x3", "asr_sepconv_fused_f16x3", "asr_sepconv_fused_f16x3"]
+    return fused
+
+
+def _replay(lib, launches, stream, times):
+    from asr_amd import _lib
+    with torch.cuda.stream(stream):
+        s = _lib.stream_ptr()
+        for _ in range(times):
+            for name, args in launches:
+                assert getattr(lib, name)(*args, s) == 0
+
+
+def test_sr_solve_next_to_the_fused_entry_kernels_on_another_stream(dev):
+    """An SR iteration that runs while entry_stem_fused_kernel / sepconv_fused_kernel occupy the chip on ANOTHER stream
+    returns the values of a quiet run, stage by stage (residuals, gradient planes, x).  Round 3 found K_fwd returning
+    garbage in lanes 48-63 of a few waves here (12 of 12 trials) while sr.hip was compiled with packed-f32 instructions;
+    round 4 (profiles/r04_hazard_matrix.txt) showed the conditions -- packed-f32 in a wave that fits beside two of those
+    kernels' waves on a SIMD -- and csrc/build.py + csrc/isa_guard.py keep every such kernel free of them
+    (tools/diag_sr_stages_under_stem.py is the long form of this test)."""
+    from asr_amd import _lib, ops, transforms as T, weights as Wt
+    from asr_amd.model import DeeplabModel
+    model = DeeplabModel(Wt.make_synthetic_weights(1234), (H, W, 3), 21, False, None)
+    fused = _fused_entry_launches(model, dev)
     lib = _lib.load()
 
     rng = np.random.RandomState(3)
@@ -171,14 +189,58 @@ def test_sr_solve_next_to_the_fused_stem_on_another_stream(dev):
         xq, wsq = one_iteration()
     torch.cuda.synchronize()
     quiet = [t.clone() for t in stages(xq, wsq)]
-    for trial in range(6):
-        with torch.cuda.stream(sa):
-            s = _lib.stream_ptr()
-            for _ in range(6):
-                for name, args in stem:
-                    assert getattr(lib, name)(*args, s) == 0
+    for aggressors, times in ((fused[:1], 6), (fused[1:], 3)):            # the stem alone (0.9 ms each), the two separable convs
+        for trial in range(6):
+            _replay(lib, aggressors, sa, times)
+            with torch.cuda.stream(sb):
+                xt, wst = one_iteration()
+            torch.cuda.synchronize()
+            for what, got, ref in zip(("residuals", "gradient planes", "x"), stages(xt, wst), quiet):
+                assert torch.equal(got, ref), (f"{aggressors[0][0]} trial {trial}: {what} differ in "
+                                               f"{int((got != ref).sum())} elements")
+
+
+def test_second_lane_kernels_next_to_the_fused_entry_kernels_on_another_stream(dev):
+    """The OTHER kernels of the second lane -- the augmentation warp, the max / mean realignment, OPM argmax, min-max, the
+    threshold and the IoU counts -- next to the same launches: bit-identical to their quiet runs."""
+    from asr_amd import _lib, ops, transforms as T, weights as Wt
+    from asr_amd.model import DeeplabModel
+    model = DeeplabModel(Wt.make_synthetic_weights(1234), (H, W, 3), 21, False, None)
+    fused = _fused_entry_launches(model, dev)
+    lib = _lib.load()
+    rng = np.random.RandomState(11)
+    img = ops.to_device(rng.rand(H, W, 3).astype(np.float32))
+    angles = rng.uniform(-0.15, 0.15, N).astype(np.float32)
+    shifts = rng.uniform(-80, 80, (N, 2)).astype(np.float32)
+    angles[0] = 0
+    shifts[0] = 0
+    rot, tr = ops.to_device(T.rotation_transforms(angles, H, W)), ops.to_device(T.translation_transforms(shifts))
+    irot, itr = (ops.to_device(T.rotation_transforms(-angles, H, W)).reshape(1, N, 8),
+                 ops.to_device(T.translation_transforms(-shifts)).reshape(1, N, 8))
+    y = ops.to_device(rng.rand(1, N, h, w).astype(np.float32))
+    logits = ops.to_device(rng.randn(N, h, w, 21).astype(np.float32))
+    label = ops.to_device((rng.rand(H, W) > 0.5).astype(np.int32) * 8, dtype=torch.int32)
+
+    def second_lane():
+        copies = ops.augment_copies(img, rot, tr)
+        mx, mean = ops.realign(y, itr, irot, (H, W), "both")
+        masks = ops.opm_argmax(logits, 8)
+        lo_hi = ops.minmax(mean)
+        th = ops.threshold(mean.reshape(H, W), 8, th_factor=0.15)
+        counts = ops.iou_counts(label, th, 8)
+        return [copies, mx, mean, masks, lo_hi, th, counts]
+
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    with torch.cuda.stream(sb):
+        quiet = second_lane()
+    torch.cuda.synchronize()
+    quiet = [torch.as_tensor(t).clone() if torch.is_tensor(t) else t for t in quiet]
+    names = ("augment_copies", "realign max", "realign mean", "opm_argmax", "minmax", "threshold", "iou_counts")
+    for trial in range(4):
+        _replay(lib, fused, sa, 3)
         with torch.cuda.stream(sb):
-            xt, wst = one_iteration()
+            got = second_lane()
         torch.cuda.synchronize()
-        for what, got, ref in zip(("residuals", "gradient planes", "x"), stages(xt, wst), quiet):
-            assert torch.equal(got, ref), f"trial {trial}: {what} differ in {int((got != ref).sum())} elements"
+        for what, a, b in zip(names, got, quiet):
+            same = torch.equal(a, b) if torch.is_tensor(a) else (np.asarray(a) == np.asarray(b)).all()
+            assert same, f"trial {trial}: {what} differs from its quiet run"

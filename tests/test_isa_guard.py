@@ -1,0 +1,75 @@
+"""CPU-side guard over the machine code of libasr_hip.so (csrc/isa_guard.py).
+
+Round 3 found SR solves returning garbage in lanes 48-63 next to the fused entry-flow kernels of another stream; round 4's
+variant matrix (profiles/r04_hazard_matrix.txt) established the necessary conditions -- the victim wave executes packed-f32
+instructions AND fits beside two waves of those kernels on a SIMD -- and the library is built so that no kernel meets both.
+These tests disassemble the library that was actually built and fail if a source edit or a compiler update changes that.
+"""
+import importlib.util
+import os
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "deeplabv3plus-augmented-superresolution_amd")
+
+
+def _guard():
+    spec = importlib.util.spec_from_file_location("asr_isa_guard", os.path.join(PKG, "csrc", "isa_guard.py"))
+    g = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(g)
+    return g
+
+
+@pytest.fixture(scope="module")
+def guard():
+    import __graft_entry__
+    __graft_entry__.build()
+    g = _guard()
+    try:
+        g._tool("llvm-objdump")
+    except g.ToolMissing as e:                      # the ROCm image has them; a bare box does not
+        pytest.skip(str(e))
+    return g
+
+
+def test_product_library_has_no_forbidden_instruction_form(guard):
+    bad = guard.violations()
+    assert not bad, "\n".join(f"{rule}: {inst}  in {kern}" for kern, inst, rule in bad[:20])
+
+
+def test_packed_f32_only_in_kernels_too_large_to_share_a_simd_with_the_fused_kernels(guard):
+    s = guard.summary()
+    assert s["packed_f32"] > 1000, s                                      # the depthwise kernels do use them
+    assert s["packed_f32_scalar_source"] == 0, s
+    assert s["fewest_registers_of_a_kernel_with_packed_f32"] > guard.CORESIDENT_MAX_VGPR, s
+    # the kernels that run on the second lane (SR solver, warps, reductions) contain none at all, whatever their size
+    lib = os.path.join(PKG, "libasr_hip.so")
+    second_lane = ("sr_", "warp_affine", "augment_copies", "opm_", "argmax", "minmax", "threshold", "iou_counts", "class_")
+    for kern, insts in guard.disassemble(lib).items():
+        if any(t in kern for t in second_lane):
+            assert not any(guard._PK_F32.search(i) for i in insts), kern
+
+
+def test_mode_register_is_written_only_by_the_kernels_that_split_with_saturating_conversions(guard):
+    writers = guard.summary()["mode_writers"]
+    assert writers, "the saturating split (asr_common.h) is expected in the fused entry-flow kernels"
+    for k in writers:
+        assert any(m in k for m in guard.MODE_WRITERS), k
+
+
+def test_the_rules_catch_a_library_that_breaks_them(guard, tmp_path):
+    """The guard must not be vacuous: a library with the round-3 form of sr.hip (packed-f32, scalar sources, 90 registers in
+    K_fwd) is rejected."""
+    import subprocess
+    spec = importlib.util.spec_from_file_location("asr_build", os.path.join(PKG, "csrc", "build.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    obj = str(tmp_path / "sr_pk.o")
+    lib = str(tmp_path / "libbad.so")
+    cmd = [b._hipcc()] + b.COMMON + ["-ffp-contract=off", "-c", os.path.join(PKG, "csrc", "sr.hip"), "-o", obj]
+    subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
+    subprocess.run([b._hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, obj], check=True, stderr=subprocess.DEVNULL)
+    bad = guard.violations(lib)
+    assert len(bad) > 100
+    assert any("sr_forward_residual_kernel" in k for k, _i, _r in bad)

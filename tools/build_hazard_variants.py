@@ -1,0 +1,106 @@
+#!/usr/bin/env python3
+"""Variant libraries for the localisation of the lanes-48-63 interaction (round 4).
+
+The victim (K_fwd of the SR solver with packed-f32 instructions that take SGPR operands) and the aggressor (a kernel that
+runs the saturating split of asr_common.h on another stream) are varied ONE ingredient at a time; every variant library is
+the product's objects (csrc/build/*.o) with one or two translation units replaced.  tools/diag_sr_stages_under_stem.py is
+then run once per library (ASR_LIB=...), 12 one-iteration solves each: "N of 12 moved".
+
+    python tools/build_hazard_variants.py          # cross-compiles here (no GPU needed); libraries land next to libasr_hip.so
+                                                   # as libasr_hz_<name>.so and travel to the GPU box with the snapshot
+
+victim side (sr.hip; -ffp-contract=off always):
+    pk       packed-f32 allowed, transform coefficients in SGPRs (the round-3 form that moved 44 of 44 times)
+    pkv      packed-f32 allowed, coefficients pinned in VGPRs (-DASR_TF_IN_VGPR): K_fwd has no SGPR-operand packed op left
+    (product) no packed-f32 at all
+aggressor side (layers.hip = entry_stem_fused_kernel, sepconv.hip, gemm.hip):
+    nosetreg    -DASR_DIAG_NO_SETREG      MODE.FP16_OVFL is never written; packed converts stay
+    scalar      -DASR_DIAG_SCALAR_SPLIT   MODE.FP16_OVFL written, value-by-value clamped split (no v_cvt_pk / SDWA / pk_add from it)
+    nosdwa      -mllvm -amdgpu-sdwa-peephole=0   packed split, MODE written, no SDWA forms
+    sepconv_pk  -DASR_SEPCONV_PACKED_SPLIT=1      the fused separable conv on the packed split (round 3: "joins the stem")
+"""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "deeplabv3plus-augmented-superresolution_amd")
+CSRC = os.path.join(PKG, "csrc")
+sys.path.insert(0, CSRC)
+import build as B  # noqa: E402
+
+OBJ = os.path.join(CSRC, "build_hz")
+FP = ["-ffp-contract=off"]
+NOSDWA = ["-mllvm", "-amdgpu-sdwa-peephole=0"]
+# object name -> (source, flags)
+OBJECTS = {
+    "sr_pk": ("sr.hip", FP),
+    "sr_pkv": ("sr.hip", FP + ["-DASR_TF_IN_VGPR"]),
+    "layers_nosetreg": ("layers.hip", ["-DASR_DIAG_NO_SETREG"]),
+    "layers_scalar": ("layers.hip", ["-DASR_DIAG_SCALAR_SPLIT"]),
+    "layers_nosdwa": ("layers.hip", NOSDWA),
+    "layers_scalar_nosetreg": ("layers.hip", ["-DASR_DIAG_SCALAR_SPLIT", "-DASR_DIAG_NO_SETREG"]),
+    "sepconv_pk": ("sepconv.hip", ["-DASR_SEPCONV_PACKED_SPLIT=1"]),
+    "sepconv_pk_nosetreg": ("sepconv.hip", ["-DASR_SEPCONV_PACKED_SPLIT=1", "-DASR_DIAG_NO_SETREG"]),
+    "sepconv_clamped_setreg": ("sepconv.hip", ["-DASR_SEPCONV_PACKED_SPLIT=1", "-DASR_DIAG_SCALAR_SPLIT"]),
+    # second matrix: how many registers the waves allocate, i.e. who can share a SIMD's 512 with whom (nothing else changes)
+    "layers_v256": ("layers.hip", ["-DASR_DIAG_STEM_TOP_VGPR=255"]),           # two stem waves fill the file: no co-resident wave
+    "layers_v216": ("layers.hip", ["-DASR_DIAG_STEM_TOP_VGPR=215"]),           # 80 left: K_fwd (96 with packed-f32) does not fit
+    "layers_v208": ("layers.hip", ["-DASR_DIAG_STEM_TOP_VGPR=207"]),           # 96 left: it just fits, at base 416
+    "sepconv_pk_v216": ("sepconv.hip", ["-DASR_SEPCONV_PACKED_SPLIT=1", "-DASR_DIAG_SEPCONV_TOP_VGPR=215"]),
+    # third matrix: the SAME benign aggressor (clamped sepconv<64>, 182 registers: K_fwd beside it at base 368 never moved) with
+    # its allocation raised, so that the co-resident K_fwd wave lands at base 384 / 400 / 416 (sepconv<128> has 212: hosts nothing)
+    "sepconv_v192": ("sepconv.hip", ["-DASR_DIAG_SEPCONV_TOP_VGPR=191"]),
+    "sepconv_v200": ("sepconv.hip", ["-DASR_DIAG_SEPCONV_TOP_VGPR=199"]),
+    "sepconv_v208": ("sepconv.hip", ["-DASR_DIAG_SEPCONV_TOP_VGPR=207"]),
+    "sr_pk_v112": ("sr.hip", FP + ["-DASR_DIAG_KFWD_TOP_VGPR=111"]),
+    "sr_nopk_v96": ("sr.hip", FP + B.NO_PK_F32 + ["-DASR_DIAG_KFWD_TOP_VGPR=95"]),     # the product's K_fwd, allocation raised from 64 to 96
+}
+# library name -> {product object replaced: variant object}
+LIBS = {
+    "pk": {"sr": "sr_pk"},                                                     # positive control: expect 12 of 12
+    "pk_nosetreg": {"sr": "sr_pk", "layers": "layers_nosetreg"},
+    "pk_scalar": {"sr": "sr_pk", "layers": "layers_scalar"},
+    "pk_nosdwa": {"sr": "sr_pk", "layers": "layers_nosdwa"},
+    "pk_scalar_nosetreg": {"sr": "sr_pk", "layers": "layers_scalar_nosetreg"},  # negative control for the stem: expect 0
+    "pkv": {"sr": "sr_pkv"},                                                   # packed math on vector operands only
+    "pk_sepconv_pk": {"sr": "sr_pk", "sepconv": "sepconv_pk"},                 # replay the sepconv launches, not the stem
+    "pk_sepconv_pk_nosetreg": {"sr": "sr_pk", "sepconv": "sepconv_pk_nosetreg"},
+    "pk_sepconv_clamped_setreg": {"sr": "sr_pk", "sepconv": "sepconv_clamped_setreg"},
+    "pk_stem256": {"sr": "sr_pk", "layers": "layers_v256"},
+    "pk_stem216": {"sr": "sr_pk", "layers": "layers_v216"},
+    "pk_stem208": {"sr": "sr_pk", "layers": "layers_v208"},
+    "pk_sepconv_pk_v216": {"sr": "sr_pk", "sepconv": "sepconv_pk_v216"},
+    "pk112": {"sr": "sr_pk_v112"},
+    "pk_sepconv192": {"sr": "sr_pk", "sepconv": "sepconv_v192"},
+    "pk_sepconv200": {"sr": "sr_pk", "sepconv": "sepconv_v200"},
+    "pk_sepconv208": {"sr": "sr_pk", "sepconv": "sepconv_v208"},
+    "nopk96": {"sr": "sr_nopk_v96"},
+}
+
+
+def main():
+    B.build(verbose=False)                                                     # product objects up to date
+    os.makedirs(OBJ, exist_ok=True)
+    hipcc = B._hipcc()
+    for name, (src, flags) in OBJECTS.items():
+        o = os.path.join(OBJ, name + ".o")
+        s = os.path.join(CSRC, src)
+        deps = [s] + [os.path.join(CSRC, h) for h in B.HEADERS] + [os.path.abspath(__file__)]
+        if B._stale(o, deps):
+            extra = dict(B.SOURCES)[src]
+            extra = [f for f in extra if f not in B.NO_PK_F32 and f not in FP]
+            cmd = [hipcc] + B.COMMON + extra + flags + ["-c", s, "-o", o]
+            print(" ".join(cmd), flush=True)
+            B._compile(cmd)
+    prod = {os.path.splitext(src)[0]: os.path.join(CSRC, "build", os.path.splitext(src)[0] + ".o") for src, _ in B.SOURCES}
+    for lib, repl in LIBS.items():
+        objs = [os.path.join(OBJ, repl[k] + ".o") if k in repl else o for k, o in prod.items()]
+        out = os.path.join(PKG, f"libasr_hz_{lib}.so")
+        if B._stale(out, objs):
+            subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs)
+        print(out, flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -11,6 +11,7 @@ Round 3 (profiles/r03_sr_next_to_stem_diagnosis.txt): with packed-f32 instructio
 garbage in lanes 48-63 of ~130 of its 25 600 waves, 44 of 44 trials, whatever the form of the loads; without them 0 of 32.
 csrc/build.py builds sr.hip / warp.hip / reduce.hip without them; this tool now reports "0 of N moved".
 """
+import os
 import sys
 import numpy as np, torch
 sys.path.insert(0, "/root/repo")
@@ -66,10 +67,11 @@ def one_solve():
 
 
 def replay(kind, times):
+    """kind: a plan kind ("conv" = the stem launch), or "name:<entry point>" (every launch of that entry point)."""
     s = _lib.stream_ptr()
     for _ in range(times):
         for name, args, k, *_ in plan["steps"]:
-            if k == kind:
+            if k == kind or kind == "name:" + name:
                 rc = getattr(lib, name)(*args, s)
                 assert rc == 0, name
 
@@ -104,9 +106,11 @@ def describe(name, a, q):
             f"{float(a[first]):.9g} vs quiet {float(q[first]):.9g}")
 
 
-for kind, reps in (("conv", 6),):
-    if kind not in kinds:
-        continue
+# DIAG_REPLAY="conv:6" (default) | "name:asr_sepconv_fused_f16x3:3" | "name:asr_pwconv_mfma_f16x3:1" ...: what runs on the other stream
+_spec = os.environ.get("DIAG_REPLAY", "conv:6").rsplit(":", 1)
+print("library:", os.environ.get("ASR_LIB", "(product)"), "| replay:", _spec, "| launches per replay:",
+      sum(1 for st in plan["steps"] if st[2] == _spec[0] or _spec[0] == "name:" + st[0]), flush=True)
+for kind, reps in ((_spec[0], int(_spec[1])),):
     moved = 0
     for t in range(trials):
         with torch.cuda.stream(sa):

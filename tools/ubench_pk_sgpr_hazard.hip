@@ -1,0 +1,229 @@
+// Synthetic reproduction of the lanes-48-63 interaction, gfx950 only.
+//   hipcc -O2 --offload-arch=gfx950 tools/ubench_pk_sgpr_hazard.hip -o /tmp/ub && /tmp/ub [trials]
+// Round 4's variant matrix (profiles/r04_hazard_matrix.txt) showed that neither the SGPR operands of the victim's packed-f32
+// instructions nor the saturating split / MODE write of the aggressor matter: what the aggressors have in common is that two of
+// their waves leave just enough of a SIMD's 512 vector registers for ONE victim wave at the top of the file.  This program
+// tests that directly:
+//   VICTIM   256-thread workgroups whose waves allocate 96 registers and execute v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32 (vector
+//            operands only) and the unpacked v_mul_f32 on explicitly numbered registers (low: v8.., high: v84..), comparing
+//            every packed result, lane by lane, with the unpacked arithmetic.  A wave that sees a mismatch records its
+//            HW_REG_GPR_ALLOC (physical register base / size) and HW_REG_HW_ID.
+//   AGGRESSOR  one 512-thread workgroup per CU (120 KB of LDS keeps a second one out), NV registers per wave, plain v_fma
+//            loop -- no MODE write, no conversions, no MFMA, no LDS traffic.  Two of its waves per SIMD occupy registers
+//            0 .. 2 NV - 1, so a victim wave lands at base 2 NV when 512 - 2 NV >= 96.
+// Output per aggressor NV: mismatches per instruction form, the lanes, and the register bases of the waves that failed / of all.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+// bad[form * 64 + lane]; forms: 0 pk_mul low regs, 1 pk_mul high regs, 2 pk_add high, 3 pk_fma high, 4 unpacked mul high (control)
+// alloc_all[base granule 0..63], alloc_bad[base granule]: histogram of VGPR_BASE (units of 8 registers) over all / failing waves
+__global__ __launch_bounds__(256) void victim(const float* __restrict__ src, unsigned* __restrict__ bad, unsigned* __restrict__ alloc_all,
+                                              unsigned* __restrict__ alloc_bad, unsigned* __restrict__ first_bad, int iters) {
+    const int lane = threadIdx.x & 63;
+    f2 a = {src[lane] + 0.01f * (blockIdx.x & 63), src[64 + lane]}, b = {src[128 + lane], src[192 + lane] - 0.003f * (blockIdx.x & 31)};
+    unsigned nbad[5] = {0, 0, 0, 0, 0};
+    for (int it = 0; it < iters; ++it) {
+        float lx, ly, hx, hy, ax, ay, fx, fy, ux, uy;
+        asm volatile(
+            "v_mov_b32 v8, %10\n v_mov_b32 v9, %11\n v_mov_b32 v10, %12\n v_mov_b32 v11, %13\n"
+            "v_mov_b32 v84, %10\n v_mov_b32 v85, %11\n v_mov_b32 v86, %12\n v_mov_b32 v87, %13\n"
+            "v_pk_mul_f32 v[12:13], v[8:9], v[10:11]\n"
+            "v_pk_mul_f32 v[88:89], v[84:85], v[86:87]\n"
+            "v_pk_add_f32 v[90:91], v[84:85], v[86:87]\n"
+            "v_pk_fma_f32 v[92:93], v[84:85], v[86:87], v[84:85]\n"
+            "v_mul_f32 v94, v84, v86\n v_mul_f32 v95, v85, v87\n"
+            "v_mov_b32 %0, v12\n v_mov_b32 %1, v13\n v_mov_b32 %2, v88\n v_mov_b32 %3, v89\n v_mov_b32 %4, v90\n v_mov_b32 %5, v91\n"
+            "v_mov_b32 %6, v92\n v_mov_b32 %7, v93\n v_mov_b32 %8, v94\n v_mov_b32 %9, v95\n"
+            : "=&v"(lx), "=&v"(ly), "=&v"(hx), "=&v"(hy), "=&v"(ax), "=&v"(ay), "=&v"(fx), "=&v"(fy), "=&v"(ux), "=&v"(uy)
+            : "v"(a.x), "v"(a.y), "v"(b.x), "v"(b.y)
+            : "v8", "v9", "v10", "v11", "v12", "v13", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95");
+        float mx, my, sx, sy, qx, qy;                           // the unpacked arithmetic, written out so that the compiler cannot pair it
+        asm volatile("v_mul_f32 %0, %1, %2" : "=v"(mx) : "v"(a.x), "v"(b.x));
+        asm volatile("v_mul_f32 %0, %1, %2" : "=v"(my) : "v"(a.y), "v"(b.y));
+        asm volatile("v_add_f32 %0, %1, %2" : "=v"(sx) : "v"(a.x), "v"(b.x));
+        asm volatile("v_add_f32 %0, %1, %2" : "=v"(sy) : "v"(a.y), "v"(b.y));
+        asm volatile("v_fma_f32 %0, %1, %2, %1" : "=v"(qx) : "v"(a.x), "v"(b.x));
+        asm volatile("v_fma_f32 %0, %1, %2, %1" : "=v"(qy) : "v"(a.y), "v"(b.y));
+        nbad[0] += (__float_as_int(lx) != __float_as_int(mx)) | (__float_as_int(ly) != __float_as_int(my));
+        nbad[1] += (__float_as_int(hx) != __float_as_int(mx)) | (__float_as_int(hy) != __float_as_int(my));
+        nbad[2] += (__float_as_int(ax) != __float_as_int(sx)) | (__float_as_int(ay) != __float_as_int(sy));
+        nbad[3] += (__float_as_int(fx) != __float_as_int(qx)) | (__float_as_int(fy) != __float_as_int(qy));
+        nbad[4] += (__float_as_int(ux) != __float_as_int(mx)) | (__float_as_int(uy) != __float_as_int(my));
+        a.x += 0.5f;
+        b.y -= 0.25f;
+    }
+    unsigned any = 0;
+#pragma unroll
+    for (int f = 0; f < 5; ++f) {
+        if (nbad[f]) atomicAdd(&bad[f * 64 + lane], nbad[f]);
+        any |= nbad[f];
+    }
+    const unsigned alloc = __builtin_amdgcn_s_getreg(5 | (0 << 6) | (31 << 11));     // HW_REG_GPR_ALLOC, all 32 bits
+    const unsigned hwid = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));      // HW_REG_HW_ID
+    const bool wave_bad = __builtin_amdgcn_ballot_w64(any != 0) != 0;
+    if (lane == 0) {
+        atomicAdd(&alloc_all[alloc & 63], 1u);
+        if (wave_bad) {
+            atomicAdd(&alloc_bad[alloc & 63], 1u);
+            if (atomicAdd(&first_bad[0], 1u) < 8) {
+                const unsigned k = atomicAdd(&first_bad[1], 1u);
+                if (k < 8) { first_bad[2 + 2 * k] = alloc; first_bad[3 + 2 * k] = hwid; }
+            }
+        }
+    }
+}
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f16v __attribute__((ext_vector_type(16)));
+typedef unsigned u4 __attribute__((ext_vector_type(4)));
+
+// MODE: 0 v_fma only | 1 v_mfma_f32_16x16x32_f16 | 2 v_mfma_f32_32x32x16_f16 | 3 LDS 16-byte writes + reads | 4 DPP row shifts
+//       5 v_permlane16_swap | 6 global 16-byte loads + stores | 7 the packed saturating split (v_cvt_pk_f16_f32, SDWA, FP16_OVFL)
+//       8 all of them in one loop
+template <int NV, int MODE>
+__global__ __launch_bounds__(512) void aggressor(const float* __restrict__ src, float* __restrict__ sink, int iters) {
+    extern __shared__ char lds[];
+    const int tid = threadIdx.x;
+    float x = src[tid & 255], acc = 0.f;
+    if (NV == 200) asm volatile("v_mov_b32 v199, 0" ::: "v199");
+    if (NV == 208) asm volatile("v_mov_b32 v207, 0" ::: "v207");
+    if (NV == 216) asm volatile("v_mov_b32 v215, 0" ::: "v215");
+    if (NV == 128) asm volatile("v_mov_b32 v127, 0" ::: "v127");
+    if (NV == 160) asm volatile("v_mov_b32 v159, 0" ::: "v159");
+    if (MODE == 7 || MODE == 8) __builtin_amdgcn_s_setreg(1 | (23 << 6), 1);
+    f4 m4 = {0.f, 0.f, 0.f, 0.f};
+    f16v m16;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) m16[i] = 0.f;
+    h8 fa;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) fa[i] = (_Float16)(0.01f * (tid & 63) + 0.1f * i);
+    u4 q = {(unsigned)tid, 1u, 2u, 3u};
+    unsigned uacc = 0;
+    const u4* gsrc = reinterpret_cast<const u4*>(src);
+    u4* gdst = reinterpret_cast<u4*>(sink + (1 << 20)) + blockIdx.x * 512 + tid;      // sink holds 4 M floats: [1 M, 1 M + grid * 2048)
+    for (int it = 0; it < iters; ++it) {
+        if (MODE == 0 || MODE == 8) {
+            acc = acc * 1.0001f + x;
+            x += 0.001f;
+        }
+        if (MODE == 1 || MODE == 8) m4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa, fa, m4, 0, 0, 0);
+        if (MODE == 2 || MODE == 8) m16 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, fa, m16, 0, 0, 0);
+        if (MODE == 3 || MODE == 8) {
+            reinterpret_cast<u4*>(lds)[tid + 512 * (it & 7)] = q;
+            __builtin_amdgcn_s_barrier();
+            q += reinterpret_cast<u4*>(lds)[((tid * 5) & 511) + 512 * (it & 7)];
+        }
+        if (MODE == 4 || MODE == 8) {
+            q.x += __builtin_amdgcn_mov_dpp((int)q.y, 0x111, 0xF, 0xF, true);
+            q.y += __builtin_amdgcn_mov_dpp((int)q.x, 0x101, 0xF, 0xF, true);
+        }
+        if (MODE == 5 || MODE == 8) {
+            const auto sw = __builtin_amdgcn_permlane16_swap(q.z, q.w, false, false);
+            q.z = sw[0] + 1u;
+            q.w = sw[1] + 3u;
+        }
+        if (MODE == 6 || MODE == 8) {
+            const u4 g = gsrc[(tid + it) & 127];
+            uacc += g.x + g.w;
+            if ((it & 15) == 0) *gdst = q;
+        }
+        if (MODE == 7 || MODE == 8) {
+            f2 a = {x + (float)it, acc + 1.5f}, b = {x * 3.f, (float)it * 0.37f};
+            typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+            const h2 ha = __builtin_convertvector(a, h2), hb = __builtin_convertvector(b, h2);
+            const f2 ra = a - __builtin_convertvector(ha, f2), rb = b - __builtin_convertvector(hb, f2);
+            const h2 la = __builtin_convertvector(ra, h2), lb = __builtin_convertvector(rb, h2);
+            uacc += __builtin_bit_cast(unsigned, ha) + 3u * __builtin_bit_cast(unsigned, hb) + 5u * __builtin_bit_cast(unsigned, la) +
+                    7u * __builtin_bit_cast(unsigned, lb);
+            x += 0.001f;
+        }
+    }
+    float r = acc + (float)uacc + m4[0] + m4[1] + m4[2] + m4[3] + (float)(q.x + q.y + q.z + q.w);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) r += m16[i];
+    sink[blockIdx.x * 512 + tid] = r;
+}
+
+template <int NV, int MODE>
+static void launch_aggr(hipStream_t s, const float* src, float* sink, int grid, int iters) {
+    const int ldsb = 120 * 1024;
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(aggressor<NV, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, ldsb));
+    hipLaunchKernelGGL((aggressor<NV, MODE>), dim3(grid), dim3(512), ldsb, s, src, sink, iters);
+}
+
+int main(int argc, char** argv) {
+    const int trials = argc > 1 ? atoi(argv[1]) : 6;
+    hipStream_t sa, sb;
+    CK(hipStreamCreateWithFlags(&sa, hipStreamNonBlocking));
+    CK(hipStreamCreateWithFlags(&sb, hipStreamNonBlocking));
+    float *src, *sink;
+    unsigned* stats;                                            // bad[320] | alloc_all[64] | alloc_bad[64] | first_bad[18]
+    CK(hipMalloc(&src, 512 * 4)); CK(hipMalloc(&sink, (size_t)4 << 22)); CK(hipMalloc(&stats, 512 * 4));
+    std::vector<float> hs(512);
+    for (int i = 0; i < 512; ++i) hs[i] = 0.0137f * i - 1.3f;
+    CK(hipMemcpy(src, hs.data(), 2048, hipMemcpyHostToDevice));
+    const int vgrid = 6400, viters = 32;                        // 25 600 victim waves per launch, like one K_fwd launch
+    const int agrid = 256;
+    struct Aggr { void (*fn)(hipStream_t, const float*, float*, int, int); int nv, iters; const char* what; };
+    const Aggr aggr[] = {
+        {launch_aggr<200, 0>, 200, 400000, "v_fma only"},
+        {launch_aggr<200, 1>, 200, 800000, "v_mfma_f32_16x16x32_f16"},
+        {launch_aggr<200, 2>, 200, 400000, "v_mfma_f32_32x32x16_f16"},
+        {launch_aggr<200, 3>, 200, 30000, "LDS 16-byte writes + reads"},
+        {launch_aggr<200, 4>, 200, 200000, "DPP row shifts"},
+        {launch_aggr<200, 5>, 200, 200000, "v_permlane16_swap"},
+        {launch_aggr<200, 6>, 200, 30000, "global 16-byte loads + stores"},
+        {launch_aggr<200, 7>, 200, 100000, "packed saturating split (FP16_OVFL)"},
+        {launch_aggr<200, 8>, 200, 60000, "all of them"},
+        {launch_aggr<216, 8>, 216, 20000, "all of them (victims cannot co-reside)"},
+        {launch_aggr<160, 8>, 160, 20000, "all of them"},
+    };
+    const int naggr = sizeof(aggr) / sizeof(aggr[0]);
+    const char* forms[5] = {"pk_mul v8..", "pk_mul v84..", "pk_add v84..", "pk_fma v84..", "v_mul v84.. (unpacked)"};
+    for (int m = -1; m < naggr; ++m) {
+        CK(hipMemset(stats, 0, 512 * 4));
+        hipEvent_t e0, e1, v0, v1;
+        CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1)); CK(hipEventCreate(&v0)); CK(hipEventCreate(&v1));
+        float ms_a = 0.f, ms_v = 0.f;
+        for (int t = 0; t < trials; ++t) {
+            if (m >= 0) {
+                CK(hipEventRecord(e0, sa));
+                aggr[m].fn(sa, src, sink, agrid, aggr[m].iters);
+                CK(hipEventRecord(e1, sa));
+            }
+            CK(hipEventRecord(v0, sb));
+            for (int k = 0; k < 8; ++k)
+                hipLaunchKernelGGL(victim, dim3(vgrid), dim3(256), 0, sb, src, stats, stats + 320, stats + 384, stats + 448, viters);
+            CK(hipEventRecord(v1, sb));
+            CK(hipGetLastError());
+            CK(hipDeviceSynchronize());
+            if (m >= 0) CK(hipEventElapsedTime(&ms_a, e0, e1));
+            CK(hipEventElapsedTime(&ms_v, v0, v1));
+        }
+        unsigned h[512];
+        CK(hipMemcpy(h, stats, 2048, hipMemcpyDeviceToHost));
+        if (m < 0) printf("no aggressor (victims %.2f ms per 8 launches):\n", ms_v);
+        else printf("aggressor: %s, %d registers per wave (%.2f ms per launch; victims %.2f ms per 8 launches):\n", aggr[m].what, aggr[m].nv, ms_a, ms_v);
+        for (int f = 0; f < 5; ++f) {
+            unsigned long long tot = 0; int lo = 64, hi = -1;
+            for (int l = 0; l < 64; ++l) if (h[f * 64 + l]) { tot += h[f * 64 + l]; lo = l < lo ? l : lo; hi = l > hi ? l : hi; }
+            if (tot) printf("    %-24s %llu mismatching results, lanes %d..%d\n", forms[f], tot, lo, hi);
+            else printf("    %-24s 0\n", forms[f]);
+        }
+        printf("    victim waves by VGPR base (registers: waves [failing]):");
+        for (int g = 0; g < 64; ++g) if (h[320 + g]) printf(" %d: %u [%u]", g * 8, h[320 + g], h[384 + g]);
+        printf("\n");
+        for (unsigned k = 0; k < 8 && k < h[449]; ++k) printf("    failing wave: GPR_ALLOC 0x%08x HW_ID 0x%08x\n", h[450 + 2 * k], h[451 + 2 * k]);
+        fflush(stdout);
+    }
+    return 0;
+}
