@@ -277,33 +277,51 @@ def launch_ranks(args):
     return subprocess.call(cmd, env=env)
 
 
-def profile_provenance():
-    """The committed PMC summaries (profiles/r*_pmc_{traffic,sq}.json) were taken at some commit; `traffic` and
-    `mfma_util_pmc` are quoted from them only while the kernel sources are unchanged since.  Each summary carries the commit
-    it was taken at ("_commit"); `git diff --quiet <commit> -- csrc/` decides.  Outside a git checkout (the GPU boxes get a
-    snapshot without .git) the stamp file profiles/csrc.sha256, written by tools/profile_round.sh next to the summaries, is
-    compared with the hash of the sources as they are."""
-    import glob
+# kernel family of the profile -> the translation unit its kernels are compiled from
+FAMILY_UNIT = {"pw16": "gemm", "pw16s": "gemm", "pw": "gemm", "dw": "dwconv", "sepconv": "sepconv", "conv": "layers",
+               "misc": "layers", "sr": "sr"}
+
+
+def unit_hashes():
+    """sha256 per translation unit of the library: its source, every shared header and its compile flags (csrc/build.py's
+    COMMON + per-file flags, which decide the code objects as much as the sources do)."""
     import hashlib
+    import importlib.util
     csrc = os.path.join(ROOT, "deeplabv3plus-augmented-superresolution_amd", "csrc")
-    h = hashlib.sha256()
-    # build.py is hashed too: its per-file flags (e.g. no packed-f32 in sr / warp / reduce) decide the code objects
-    for f in sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h")) +
-                    glob.glob(os.path.join(csrc, "*.cpp")) + [os.path.join(csrc, "build.py")]):
-        h.update(os.path.basename(f).encode())
-        with open(f, "rb") as fh:
+    spec = importlib.util.spec_from_file_location("asr_csrc_build", os.path.join(csrc, "build.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    hdr = hashlib.sha256()
+    for f in b.HEADERS:
+        with open(os.path.join(csrc, f), "rb") as fh:
+            hdr.update(fh.read())
+    out = {}
+    for src, flags in b.SOURCES:
+        h = hashlib.sha256(hdr.digest())
+        h.update(" ".join(b.COMMON + flags).encode())
+        with open(os.path.join(csrc, src), "rb") as fh:
             h.update(fh.read())
-    now = h.hexdigest()
+        out[os.path.splitext(src)[0]] = h.hexdigest()[:16]
+    return out
+
+
+def profile_provenance():
+    """The committed PMC summaries (profiles/r*_pmc_{traffic,sq}*.json) are quoted only for kernels whose TRANSLATION UNIT is
+    unchanged since they were taken: profiles/csrc.sha256 (written by tools/profile_round.sh next to the summaries) holds
+    one hash per unit -- source + shared headers + compile flags -- and the commit; a change of sr.hip neither vouches for
+    nor invalidates the GEMM counters."""
+    now = unit_hashes()
     stamp = os.path.join(ROOT, "profiles", "csrc.sha256")
-    rec = {"csrc_sha256": now[:16]}
+    rec = {"units": now, "profiled_units": {}, "profiled_at_commit": None}
     if os.path.exists(stamp):
-        with open(stamp) as fh:
-            words = fh.read().split()
-        rec["profiled_csrc_sha256"] = words[0][:16] if words else None
-        rec["profiled_at_commit"] = words[1] if len(words) > 1 else None
-        rec["current"] = bool(words) and words[0] == now
-    else:
-        rec["current"] = False
+        try:
+            with open(stamp) as fh:
+                old = json.load(fh)
+            rec["profiled_units"] = old.get("units", {})
+            rec["profiled_at_commit"] = old.get("commit")
+        except ValueError:
+            pass                                               # a stamp of an earlier format vouches for nothing
+    rec["current"] = {u: rec["profiled_units"].get(u) == h for u, h in now.items()}
     return rec
 
 
@@ -398,26 +416,34 @@ class Workload:
         torch.cuda.empty_cache()
 
 
-def rooflines(prof, provenance):
+def rooflines(prof, provenance, cfg_id=1):
     """roofline objects from the HIP-event profile of one step (engine.forward(profile=...)): algorithmic flops / bytes of
-    the launches of a kernel family / their summed launch durations."""
+    the launches of a kernel family / their summed launch durations.  PMC figures come from the summaries taken on THIS
+    config (profiles/r*_pmc_traffic.json for configs[1], r*_pmc_traffic_cfg<N>.json for configs[N]; null when there is
+    none) and only for kernel families whose translation unit is unchanged since (profile_provenance)."""
     import glob
     out = {}
     pmc, sq, pmc_path, sq_path = {}, {}, "", ""
-    if provenance.get("current"):      # quote PMC-derived figures only for the sources they were measured on
-        pmc_files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
-        sq_files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_sq.json")))
-        if pmc_files:       # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/pmc_traffic.sh), gfx950-corrected
-            pmc_path = pmc_files[-1]
-            with open(pmc_path) as fh:
-                pmc = json.load(fh)
-        if sq_files:        # rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES ... pass (tools/pmc_sq.sh)
-            sq_path = sq_files[-1]
-            with open(sq_path) as fh:
-                sq = json.load(fh)
+    suffix = "" if cfg_id == 1 else f"_cfg{cfg_id}"
+    pmc_files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]_pmc_traffic{suffix}.json")))
+    sq_files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]_pmc_sq{suffix}.json")))
+    if pmc_files:       # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/pmc_traffic.sh), gfx950-corrected
+        pmc_path = pmc_files[-1]
+        with open(pmc_path) as fh:
+            pmc = json.load(fh)
+    if sq_files:        # rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES ... pass (tools/pmc_sq.sh)
+        sq_path = sq_files[-1]
+        with open(sq_path) as fh:
+            sq = json.load(fh)
+    current = provenance.get("current", {})
 
-    def sq_lookup(prefix):
+    def vouched(kind):
+        return bool(current.get(FAMILY_UNIT.get(kind, ""), False))
+
+    def sq_lookup(kind, prefix):
         """Launch-time-weighted matrix-pipe occupancy of the entries whose kernel name starts with ``prefix``."""
+        if not vouched(kind):
+            return None
         hits = [(v, v["launches_sampled"] * v["avg_launch_us_profiled"]) for k, v in sq.items()
                 if isinstance(v, dict) and k.startswith(prefix) and v.get("mfma_pipe_busy_at_2p4ghz") is not None]
         if not hits:
@@ -428,20 +454,26 @@ def rooflines(prof, provenance):
                 "source": f"profiles/{os.path.basename(sq_path)}: SQ_VALU_MFMA_BUSY_CYCLES / (1024 pipes x launch time x "
                           "2.4 GHz) resp. / (GRBM_GUI_ACTIVE x 1024); counts K / N padding, unlike frac"}
 
-    def pmc_lookup(prefix):
+    def pmc_lookup(kind, prefix):
         """Launch-weighted mean HBM bytes of the entries whose kernel name starts with ``prefix`` (template
         arguments in the name vary by build)."""
+        if not vouched(kind):
+            return None
         hits = [(v["hbm_bytes_per_launch"], v.get("launches_sampled", 1)) for k, v in pmc.items()
                 if isinstance(v, dict) and k.startswith(prefix) and v.get("hbm_bytes_per_launch") is not None]
         return round(sum(b * n for b, n in hits) / sum(n for _, n in hits)) if hits else None
 
-    traffic_note = (f"HBM bytes per launch from profiles/{os.path.basename(pmc_path)} (separate FETCH_SIZE / WRITE_SIZE "
-                    f"passes, FETCH doubled per the gfx950 rule), taken on these kernel sources "
-                    f"(csrc sha256 {provenance.get('csrc_sha256')}, commit {provenance.get('profiled_at_commit')})"
-                    if pmc_path else
-                    "null: the committed PMC summaries were taken on other kernel sources than the ones running "
-                    f"(csrc sha256 {provenance.get('csrc_sha256')} now, {provenance.get('profiled_csrc_sha256')} profiled); "
-                    "re-run tools/profile_round.sh")
+    def traffic_note(kind):
+        unit = FAMILY_UNIT.get(kind, "?")
+        if not pmc_path:
+            return f"null: no PMC summary for configs[{cfg_id}] under profiles/ (tools/profile_round.sh takes one)"
+        if vouched(kind):
+            return (f"HBM bytes per launch from profiles/{os.path.basename(pmc_path)} (separate FETCH_SIZE / WRITE_SIZE passes, "
+                    f"FETCH doubled per the gfx950 rule), taken on this build of {unit}.hip (unit hash "
+                    f"{provenance['units'].get(unit)}, commit {provenance.get('profiled_at_commit')})")
+        return (f"null: profiles/{os.path.basename(pmc_path)} was taken on another build of {unit}.hip (unit hash "
+                f"{provenance['units'].get(unit)} now, {provenance.get('profiled_units', {}).get(unit)} profiled); re-run "
+                "tools/profile_round.sh")
 
     def gemm_roofline(kind, kernel, pmc_key, peak, peak_note):
         ms, flops, nbytes, launches = prof[kind]
@@ -449,8 +481,8 @@ def rooflines(prof, provenance):
         return {
             "kernel": kernel, "bound": "mfma", "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s",
             "frac": round(achieved / peak, 4), "peak_note": peak_note,
-            "mfma_util_pmc": sq_lookup(pmc_key),
-            "traffic": pmc_lookup(pmc_key), "traffic_note": traffic_note,
+            "mfma_util_pmc": sq_lookup(kind, pmc_key),
+            "traffic": pmc_lookup(kind, pmc_key), "traffic_note": traffic_note(kind),
             "algorithmic_bytes_per_launch": round(nbytes / launches),
             "launches": launches, "avg_launch_ms": round(ms / launches, 4),
             "algorithmic_gflop_per_launch": round(flops / launches / 1e9, 3),
@@ -477,7 +509,7 @@ def rooflines(prof, provenance):
         ms, _fl, by, launches = prof[kind]
         gbs = by / (ms * 1e-3) / 1e9
         return {"kernel": kernel, "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": pmc_lookup(pmc_key), "traffic_note": traffic_note,
+                "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": pmc_lookup(kind, pmc_key), "traffic_note": traffic_note(kind),
                 "algorithmic_bytes_per_launch": round(by / launches), "bytes_note": note,
                 "launches": launches, "avg_launch_ms": round(ms / launches, 4)}
 
@@ -537,6 +569,7 @@ def measure(cfg_id, args, rank, world, dev, weights, steps, warmup, images=None,
     elapsed = time.perf_counter() - t0
     elapsed = D.all_reduce_max(elapsed, dev)           # MAX over ranks
 
+    collective = D.collective_info(dev)                 # after the timed region: one more (untimed) all-reduce
     k_rank = max(len(D.shard_indices(images, r, world)) for r in range(world)) if images is not None else steps
     copies_total = timed_count * wl.num_aug
     rehearsal = world > 1 and torch.distributed.get_backend() != "nccl"
@@ -555,7 +588,8 @@ def measure(cfg_id, args, rank, world, dev, weights, steps, warmup, images=None,
                   if args.precision == "f16x3" else "f32"),
         "data": "synthetic",
         "config": {
-            "workload": (f"{cfg['what']}; ASR {SR_ITERS} AMSGrad iters + max-SR + mean-SR + threshold + 6 IoUs; step = 1 image = "
+            "workload": ((f"BASELINE configs[3]: {images} images sharded over {world} GPU(s), per image as " if images is not None
+                          else "") + f"{cfg['what']}; ASR {SR_ITERS} AMSGrad iters + max-SR + mean-SR + threshold + 6 IoUs; step = 1 image = "
                          f"{wl.num_aug} copies; DeepLabV3+ Xception-65 OS16, f32 activations/accumulation, seeded synthetic "
                          f"weights (class-{CLASS_ID} logit bias shifted by {wl.bias_shift:+.4f} so that class {CLASS_ID} wins "
                          "30 % of image 0)"),
@@ -573,6 +607,9 @@ def measure(cfg_id, args, rank, world, dev, weights, steps, warmup, images=None,
                             "inside an 8 px void band -- mean_ious are self-consistency figures, not segmentation quality",
         },
     }
+    out["config"]["collective"] = {k: collective[k] for k in ("backend", "world_size", "ranks_joined")}
+    out["collective"] = dict(collective, op="one all_gather of [ceil(images / ranks), 1 + 6] float64 IoU records per rank "
+                                            "(+ the MAX all-reduce of the elapsed time)")
     if rehearsal:
         out["rehearsal"] = (f"{world} ranks on {torch.cuda.device_count()} device(s), gloo collectives: exercises sharding and the "
                             "all-gather, NOT a scaling measurement")
@@ -588,7 +625,7 @@ def measure(cfg_id, args, rank, world, dev, weights, steps, warmup, images=None,
         prof = {}
         wl.step(timed[0] if timed else 0, profile=prof)
         torch.cuda.synchronize()
-        out.update(rooflines(prof, profile_provenance()))
+        out.update(rooflines(prof, profile_provenance(), cfg_id))
     sample = None
     if rank == 0 and world == 1 and want_cpu:
         out["cpu_baseline"], sample = cpu_baseline(shifted_weights(weights, CLASS_ID, wl.bias_shift), cfg)
@@ -669,6 +706,8 @@ def main():
         w32.close()
         del w32
         args.precision = saved
+        out["config"]["exact_f32_copies_per_s"] = o32["value"]      # (top-level extras are dropped by the driver's record)
+        out["config"]["exact_f32_ms_per_step"] = o32["ms_per_step"]
         out["exact_f32"] = {"value": o32["value"], "unit": "augmented-copies/s", "steps": k32, "ms_per_step": o32["ms_per_step"],
                             "note": "--precision f32: every pointwise GEMM on v_mfma_f32_32x32x2_f32, same workload and lanes"}
     if single and args.config == 1 and args.images is None and not args.no_extra_configs:

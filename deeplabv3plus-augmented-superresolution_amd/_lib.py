@@ -44,7 +44,7 @@ class SrConfig(C.Structure):
 
 
 _cfg = C.POINTER(SrConfig)
-ABI_VERSION = 2          # ASR_ABI_VERSION of include/asr_hip.h this table mirrors
+ABI_VERSION = 3          # ASR_ABI_VERSION of include/asr_hip.h this table mirrors
 
 # name -> (restype, argtypes).  Order and types mirror include/asr_hip.h exactly.
 SIGNATURES = {
@@ -96,6 +96,7 @@ SIGNATURES = {
     "asr_dwconv3x3_nhwc_f32": (_i, [_vp, _vp, _vp, _vp] + [_i] * 15 + [_vp]),
     "asr_aspp_dwconv3_nhwc_f32": (_i, [_vp] * 6 + [_i] * 11 + [_vp]),
     "asr_aspp_dwconv3_nhwc_split_f16": (_i, [_vp] * 6 + [_i] * 11 + [_vp]),
+    "asr_aspp_dwconv3_supported": (_i, [_i] * 5),
     "asr_gap_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "asr_resize_bilinear_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
 }

@@ -554,6 +554,13 @@ static int aspp_geometry(int h, int w, int rate0, int rate1, int rate2, int* g_o
     return ((w + g - 1) / g) * (g / nxg) <= AMAXCOLS && lds <= 160 * 1024;
 }
 
+extern "C" int asr_aspp_dwconv3_supported(int h, int w, int rate0, int rate1, int rate2) {
+    if (h <= 0 || w <= 0 || rate0 <= 0 || rate1 <= 0 || rate2 <= 0) return 0;
+    int g = 0, nxg = 0;
+    size_t lds = 0;
+    return aspp_geometry(h, w, rate0, rate1, rate2, &g, &nxg, &lds) && (long long)g * nxg <= 65535 ? 1 : 0;
+}
+
 static int aspp_common(bool split, const float* x, const float* w3, const float* bias3, void* y0, void* y1, void* y2, int batch,
                        int h, int w, int c, int rate0, int rate1, int rate2, int ldx, int ldy, int pre_relu, int post_relu,
                        asr_stream_t stream) {

@@ -69,6 +69,19 @@ def all_reduce_max(value, device):
     return float(t.item())
 
 
+def collective_info(device):
+    """What actually carried the collectives of this run: the backend torch.distributed was initialised with, the world
+    size it reports, and the number of ranks that answered one all-reduce(SUM) of a 1 -- on a real node "nccl" (= RCCL over
+    xGMI) with ranks_joined == n_gpus; "none" / 1 in a single process."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return {"backend": "none", "world_size": 1, "ranks_joined": 1, "payload_device": "none"}
+    dev = collective_device(device)
+    one = torch.ones(1, dtype=torch.int64, device=dev)
+    dist.all_reduce(one, op=dist.ReduceOp.SUM)
+    return {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "ranks_joined": int(one.item()),
+            "payload_device": dev.type}
+
+
 def shard_indices(num_images, rank, world):
     """Global image indices owned by ``rank`` (round-robin, like dealing the reference's loop)."""
     return list(range(rank, num_images, world))

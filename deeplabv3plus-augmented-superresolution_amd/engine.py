@@ -101,7 +101,7 @@ class DeeplabEngine:
         plane).  Every combination computes the same layers; results agree to f32 rounding.
         precision: 'f32' = v_mfma_f32_32x32x2_f32 everywhere (exact f32 fmaf chains);
         'f16x3' = split-f16 MFMA (hi*hi + hi*lo + lo*hi, f32 accumulate; f32-grade results, ~2.4x faster)
-        for the pointwise GEMMs with more than 64 output channels.  Default: $ASR_PRECISION or 'f16x3'."""
+        for the pointwise GEMMs with more than 32 output channels (the logits stay on exact f32).  Default: $ASR_PRECISION or 'f16x3'."""
         self.device = device or _lib.require_gpu()
         if disable is None:
             disable = [v for v in os.environ.get("ASR_DISABLE", "").split(",") if v]
@@ -453,8 +453,10 @@ class DeeplabEngine:
         release(pp)
         pw(x, "aspp0", out=cat, out_off=256, relu=True)
         rates = self.atrous_rates
-        g = int(np.gcd.reduce(rates))
-        if (-(-fh // g) * -(-fw // g) + 1) * 128 + 256 <= 160 * 1024 and "fused_aspp" not in self.disabled:
+        # the library's own geometry check (LDS per residue class AND its column limit), so the plan never meets
+        # ASR_ERR_UNSUPPORTED at run time: planes it cannot stage take the three-launch path below
+        fused_ok = bool(_lib.load().asr_aspp_dwconv3_supported(fh, fw, int(rates[0]), int(rates[1]), int(rates[2])))
+        if fused_ok and "fused_aspp" not in self.disabled:
             # the three dilated depthwise convs read the same input: one fused launch stages each residue class of the
             # plane (modulo gcd(rates), on which the taps close) in LDS once -- input read from HBM 1x instead of 3x, on
             # planes of any size (csrc/dwconv.hip: aspp_dw3_phase_kernel)

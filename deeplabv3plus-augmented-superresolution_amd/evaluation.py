@@ -8,7 +8,7 @@ import os
 import numpy as np
 
 from . import distributed as D
-from .superresolution_scripts.superres_utils import DATA_EXTS, compute_SR, load_SR_data
+from .superresolution_scripts.superres_utils import DATA_EXTS, compute_SR, load_SR_data, probe_SR_data
 from .utils import compute_IoU, load_image
 
 
@@ -40,21 +40,20 @@ def evaluate_precomputed(sr, paths, gt_dir, standard_dir=None, num_aug=100, clas
     reference's ``continue`` (SR_single_class.py:85-90); a VALID image whose IoUs are NaN (class absent from both masks)
     keeps its row, so the mean over the valid rows is NaN exactly when the reference's np.mean is.
 
-    Validity is what ``load_SR_data`` itself decides -- each rank loads the files of its own shard once (no second
-    probe, no rank opens another rank's files) -- and is all-gathered BEFORE any solve, together with the number of
-    Adam solves each file will run (two for slice_max files: class map and max map).  ``sr.optimizer``'s global step
+    Validity is what ``load_SR_data`` would decide, read from each file's HEADERS (``probe_SR_data``: no mask is loaded, no
+    rank opens another rank's files), so host memory stays at ONE image's maps whatever the shard size, like the
+    reference's loop -- and it is all-gathered BEFORE any solve, together with the number of Adam solves each file will run
+    (two for slice_max files: class map and max map).  Each valid file is then loaded once, when its turn comes.  ``sr.optimizer``'s global step
     counter is then set per image to what the reference's sequential loop would have reached: num_iter * (solves of the
     valid files before it); a skipped file runs no solve there, so it does not advance the counter here either, and
     sharding changes no update."""
     mine = D.shard_indices(len(paths), rank, world)
-    loaded, flags = {}, []
+    flags = []
     for g in mine:
-        try:
-            loaded[g] = load_SR_data(paths[g], num_aug=num_aug)
-            flags.append([1.0, 2.0 if loaded[g][1] is not None else 1.0])
-        except Exception:
+        ok, n_solves = probe_SR_data(paths[g], num_aug=num_aug)
+        if not ok:
             print(f"File: {paths[g]} is invalid, skipping...")
-            flags.append([0.0, 0.0])
+        flags.append([1.0 if ok else 0.0, float(n_solves)])
     status = D.all_gather_rows(mine, flags, len(paths), 2)                    # [files, (valid, solves)] on every rank
     valid = np.nan_to_num(status[:, 0]) > 0.5
     solves = np.where(valid, np.nan_to_num(status[:, 1]), 0.0).astype(np.int64)
@@ -64,7 +63,7 @@ def evaluate_precomputed(sr, paths, gt_dir, standard_dir=None, num_aug=100, clas
         if not valid[g]:
             records.append([np.nan] * len(D.IOU_FIELDS))
             continue
-        class_masks, max_masks, angles, shifts, filename = loaded.pop(g)
+        class_masks, max_masks, angles, shifts, filename = load_SR_data(paths[g], num_aug=num_aug)
         sr.optimizer.optimizer.iterations = int(before[g]) * sr.num_iter
         true_mask = load_image(os.path.join(gt_dir, f"{filename}.png"), image_size=img_size, normalize=False, is_png=True,
                                resize_method="nearest")

@@ -250,6 +250,18 @@ def shapes(path):
     return datasets
 
 
+def header(path):
+    """-> (shapes {"group/name": shape tuple}, attrs) from the object headers alone: like read() without touching a dataset's
+    bytes (the file is memory-mapped), for callers that only need to know what a file holds."""
+    import mmap
+    with open(path, "rb") as f, mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ) as buf:
+        r = _Reader(buf)
+        r.shapes_only = True
+        datasets, attrs = {}, {}
+        r.visit(r.root_header, "", datasets, attrs)
+    return datasets, attrs
+
+
 def read(path):
     """-> (datasets {"group/sub/name": ndarray}, attrs {"/" | "group" | "group/name": {attr: value}})."""
     with open(path, "rb") as f:

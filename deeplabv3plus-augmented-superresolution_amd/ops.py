@@ -199,6 +199,10 @@ def sr_solve(x, y, rot_tf, trans_tf, inv_rot_tf, inv_trans_tf, alphas, lambdas, 
                 lib.asr_sr_solve_workspace_bytes_cfg(b, n, H, W, h, w, C.byref(cfg)))
     if state is not None and "ws" in state:
         ws, m, v, vhat = state["ws"], state["m"], state["v"], state["vhat"]
+        if m.shape != x.shape:
+            raise AsrError(f"sr_solve: state holds optimiser slots of shape {tuple(m.shape)}, x is {tuple(x.shape)}")
+        if ws.numel() * 4 < ws_bytes:       # another plane_chunk / copy count than the call that sized it
+            ws = state["ws"] = torch.empty((ws_bytes + 3) // 4, dtype=f32, device=x.device)
     else:
         ws = torch.empty((ws_bytes + 3) // 4, dtype=f32, device=x.device)
         init = slot_init or {}

@@ -51,14 +51,15 @@ class HotPath:
         h, w, _ = image_dev.shape
         eng = self.model.engine
         bs = min(self.batch_size, n)
-        fh, fw = h // eng.output_stride, w // eng.output_stride
-        y = torch.empty((1, n, fh, fw), dtype=torch.float32, device=image_dev.device)
-        ymax = torch.empty_like(y) if self.mode == "slice_max" else None
+        y = ymax = None                     # [1, N, fh, fw], allocated from the first batch's logits: their size depends on the
         res = {"_masks": torch.empty((len(self.MASK_KEYS),) + tuple(out_hw), dtype=torch.int32, device=image_dev.device)}
         for i in range(0, n, bs):
             k = min(bs, n - i)
             copies = au.augment_on_device(image_dev, angles[i:i + k], shifts[i:i + k], out=eng.input_view(k, h, w, lane))
             preds = self.model.predict_device(copies, batch_size=k, profile=profile, lane=lane, clone=False)  # logits stay there
+            if y is None:                   # decoder / upsampling options, not only on the backbone's stride
+                y = torch.empty((1, n) + tuple(preds.shape[1:3]), dtype=torch.float32, device=image_dev.device)
+                ymax = torch.empty_like(y) if self.mode == "slice_max" else None
             if i == 0 and want_standard:
                 res["standard"] = self.standard_mask(self.model.logits_of(preds, 0), out_hw, out=res["_masks"][0])
             au.output_processing(preds, self.class_id, self.mode, out=y[0, i:i + k],

@@ -164,6 +164,34 @@ def check_validity(file, num_aug=100):
 check_hdf5_validity = check_validity          # the reference's name (superres_utils.py:108)
 
 
+def probe_SR_data(filepath, num_aug=100):
+    """What load_SR_data WOULD do with this file, from its headers alone (no mask is read): (valid, solves) -- valid exactly
+    when load_SR_data would not raise (readable, every array dataset with at least num_aug entries, name and mode present),
+    solves = the Adam solves an evaluation of it runs (2 for slice_max files: class map and max map, else 1).  Used by the
+    sharded evaluation loop, which must know both for EVERY file before its first solve (evaluation.py) and must not hold a
+    shard's worth of masks in host memory to find out."""
+    try:
+        if str(filepath).endswith(".npz"):
+            file = _open_SR_file(filepath)                      # (the .npz container has no cheap header; stage-1 default is .hdf5)
+            shapes = {k: np.shape(v) for k, v in file.items()}
+            mode = str(file["mode"])
+            str(file["filename"])
+        else:
+            shapes, attrs = hdf5_lite.header(filepath)
+            root = attrs.get("/", {})
+            mode = str(root["mode"])
+            str(root["filename"])
+        for key in ("class_masks", "angles", "shifts") + (("max_masks",) if mode == "slice_max" else ()):
+            if key not in shapes:
+                return False, 0
+        for key in ("class_masks", "max_masks", "angles", "shifts"):
+            if key in shapes and (len(shapes[key]) == 0 or shapes[key][0] < num_aug):
+                return False, 0
+        return True, 2 if mode == "slice_max" else 1
+    except Exception:
+        return False, 0
+
+
 def load_SR_data(filepath, num_aug=100, global_normalize=True):
     """Returns (class_masks [N,h,w,1], max_masks | None, angles, shifts, filename) as host arrays;
     argmax / slice_max masks are min-max normalised to [0,1] (superres_utils.py:183-206)."""

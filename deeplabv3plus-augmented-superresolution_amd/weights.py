@@ -213,6 +213,20 @@ def save_weights(path, weights):
     np.savez(path, **weights)
 
 
+def keras_variable_name(dataset_path):
+    """HDF5 dataset path of a Keras weight file -> "{layer}/{variable}", or None for what is not a layer variable.
+    save_weights() layout: <layer>/<layer>/<variable>:0; a full-model file keeps the same tree under model_weights/ (and
+    the optimizer state under optimizer_weights/, which is ignored)."""
+    parts = dataset_path.strip("/").split("/")
+    if parts[0] == "optimizer_weights":
+        return None
+    if parts[0] == "model_weights":
+        parts = parts[1:]
+    if len(parts) < 2:
+        return None
+    return f"{parts[0]}/{parts[-1].split(':')[0]}"
+
+
 def load_weights(path):
     """Local file only: an .npz with ``{layer}/{variable}`` keys, or a Keras ``.h5`` weight file (the format of the
     bonlime checkpoint the reference downloads, model.py:129-145: groups ``<layer>/<layer>/<variable>:0``), read with
@@ -225,14 +239,9 @@ def load_weights(path):
         datasets, _ = hdf5_lite.read(path)
         out = {}
         for name, value in datasets.items():
-            parts = name.split("/")
-            if parts[0] in ("model_weights", "optimizer_weights"):      # full-model .h5: weights live one level down
-                if parts[0] == "optimizer_weights":
-                    continue
-                parts = parts[1:]
-            if len(parts) < 2:
-                continue
-            out[f"{parts[0]}/{parts[-1].split(':')[0]}"] = np.asarray(value)
+            key = keras_variable_name(name)
+            if key is not None:
+                out[key] = np.asarray(value)
         if not out:
             raise ValueError(f"{path}: no '<layer>/.../<variable>' datasets found")
         return out

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define ASR_ABI_VERSION 2
+#define ASR_ABI_VERSION 3
 
 #define ASR_OK 0
 #define ASR_ERR_INVALID_ARG (-1)
@@ -310,6 +310,12 @@ int asr_dwconv3x3_nhwc_split_f16(const float* x, const float* w, const float* bi
 int asr_pwconv_mfma_f16x3_presplit(const void* x_split, const float* w_packed, const float* bias, const float* residual,
                                    float* y, int64_t m, int k, int n, int ldx_chunks, int ldy, int ldres, int relu,
                                    asr_stream_t stream);
+
+/* 1 when asr_aspp_dwconv3_nhwc_{f32,split_f16} can run an h x w plane at these three rates (a residue class of the plane
+ * modulo gcd(rates) must fit the CU's LDS in one of the kernel's column groupings), else 0: the caller then runs the three
+ * branches (model.py:214-221) as separate asr_dwconv3x3_nhwc_f32 launches.  Host arithmetic only -- no device call, no
+ * stream; the same function the launchers use, so a plan built on its answer never meets ASR_ERR_UNSUPPORTED for geometry. */
+int asr_aspp_dwconv3_supported(int h, int w, int rate0, int rate1, int rate2);
 
 /* asr_aspp_dwconv3_nhwc_f32 with its three outputs as split-f16 operands (ldy_chunks = c / 32; c % 32 == 0). */
 int asr_aspp_dwconv3_nhwc_split_f16(const float* x, const float* w3, const float* bias3, void* y0, void* y1, void* y2,

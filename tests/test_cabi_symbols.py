@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol(lib):
         assert hasattr(lib, name), f"{name} declared in include/asr_hip.h but not exported"
     # and the ctypes signature table covers the header one-to-one
     assert sorted(_lib.SIGNATURES) == declared
-    assert lib.asr_abi_version() == _lib.ABI_VERSION == 2
+    assert lib.asr_abi_version() == _lib.ABI_VERSION == 3
     assert lib.asr_target_arch() == b"gfx950"
 
 
@@ -84,3 +84,13 @@ def test_every_translation_unit_is_built_without_packed_f32_by_default():
     for src, fl in flags.items():
         if src.endswith(".hip"):
             assert "-packed-fp32-ops" in fl, src
+
+
+def test_aspp_geometry_query_is_host_arithmetic(lib):
+    """asr_aspp_dwconv3_supported needs no GPU: the plan asks it whether the fused ASPP depthwise kernel can stage a plane
+    (engine.py), so a plan never meets ASR_ERR_UNSUPPORTED for geometry at run time."""
+    assert lib.asr_aspp_dwconv3_supported(32, 32, 6, 12, 18) == 1          # configs[1]: 512 / 16
+    assert lib.asr_aspp_dwconv3_supported(64, 64, 6, 12, 18) == 1          # configs[4]: 1024 / 16
+    assert lib.asr_aspp_dwconv3_supported(64, 64, 12, 24, 36) == 1         # OS 8
+    assert lib.asr_aspp_dwconv3_supported(4096, 4096, 1, 2, 3) == 0        # gcd 1: the whole plane would have to fit
+    assert lib.asr_aspp_dwconv3_supported(0, 32, 6, 12, 18) == 0 and lib.asr_aspp_dwconv3_supported(32, 32, 0, 12, 18) == 0

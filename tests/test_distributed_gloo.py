@@ -137,5 +137,6 @@ def test_two_rank_evaluation_validity_and_adam_start(tmp_path):
                 assert np.isnan(table[g]).all()
             else:
                 assert np.isnan(table[g, :2]).all() and list(table[g, 2:]) == [float(start)] * 4
-    assert two[0][2] == ["1.hdf5", "3.hdf5", "5.hdf5"] and two[1][2] == ["2.hdf5", "4.hdf5"]     # own shard only, once
+    # own shard only, once, and only the VALID files (validity comes from the headers: probe_SR_data reads no mask)
+    assert two[0][2] == ["1.hdf5", "5.hdf5"] and two[1][2] == ["2.hdf5"]
     np.testing.assert_array_equal(two[0][3], one[0][3])

@@ -88,6 +88,11 @@ def test_bench_contract_line(dev):
     assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1 and "sample" in c
     assert "workload" in d["config"] and "model" not in d["config"]
     assert d["exact_f32"]["value"] > 50 and d["exact_f32"]["ms_per_step"] > 0
+    assert d["config"]["exact_f32_copies_per_s"] == d["exact_f32"]["value"]     # inside `config`: the driver's record keeps it
+    assert d["config"]["collective"] == {"backend": "none", "world_size": 1, "ranks_joined": 1}
+    # PMC traffic is quoted per config from ITS summary, and only while that kernel family's translation unit is unchanged
+    for obj in (d["roofline"], d["configs"]["4"]["roofline"]):
+        assert obj["traffic"] is None or obj["traffic"] >= 0.5 * obj["algorithmic_bytes_per_launch"], obj["traffic_note"]
     m = d["mean_ious"]                  # the SR stage solves a non-empty problem: class 8 is present and recovered
     assert m["aug_single"] > 0.3 and m["mean"] > 0.3
     assert "model-derived" in d["config"]["ground_truth"]
@@ -119,6 +124,8 @@ def test_bench_strong_scaling_odd_image_count(dev, tmp_path):
     out2 = _run([bench, "--gpus", "2", "--dump-table", t2] + common, ROOT)
     d2 = json.loads([l for l in out2.strip().splitlines() if l.startswith("{")][0])
     assert d2["n_gpus"] == 2 and d2["scaling"] == "strong" and d2["steps"] == 3 and d2["config"]["images_total"] == 5
+    assert d2["config"]["workload"].startswith("BASELINE configs[3]: 5 images sharded over 2 GPU(s)")
+    assert d2["config"]["collective"] == {"backend": "gloo", "world_size": 2, "ranks_joined": 2}
     out1 = _run([bench, "--gpus", "1", "--dump-table", t1] + common, ROOT)
     d1 = json.loads([l for l in out1.strip().splitlines() if l.startswith("{")][0])
     assert d1["steps"] == 5 and d1["scaling"] == "strong"

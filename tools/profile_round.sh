@@ -7,8 +7,9 @@
 #   pmc/summary.json, pmc_cfg4/summary.json             HBM bytes per launch (FETCH_SIZE / WRITE_SIZE in separate passes)
 #   pmc_sq/summary.json                                 matrix-pipe occupancy, wave-cycle split, LDS bank conflicts
 #   bench_default.json.log                              the default bench line (with its configs[2] / configs[4] objects)
-#   csrc.sha256                                         hash of the kernel sources these summaries were taken on (+ commit if
-#                                                       given as $2): bench.py quotes PMC figures only while it matches
+#   csrc.sha256                                         one hash per translation unit (source + headers + flags) these summaries were
+#                                                       taken on (+ commit if given as $2): bench.py quotes a kernel family's PMC
+#                                                       figures only while ITS unit matches
 # The program sits directly after "--" (no wrapper), counters are collected with --kernel-trace only.
 # Usage: tools/profile_round.sh <tag> [commit] [parts: all | stats | pmc | sq | bench (comma separated)]
 tag=${1:-r03}
@@ -20,13 +21,10 @@ out=gpurun_out/prof_$tag
 mkdir -p $out
 want() { [ "$parts" = all ] || echo ",$parts," | grep -q ",$1,"; }
 python3 - "$commit" > $out/csrc.sha256 <<'PY'
-import glob, hashlib, os, sys
-csrc = os.path.join("deeplabv3plus-augmented-superresolution_amd", "csrc")
-h = hashlib.sha256()
-for f in sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h")) + glob.glob(os.path.join(csrc, "*.cpp")) + [os.path.join(csrc, "build.py")]):
-    h.update(os.path.basename(f).encode())
-    h.update(open(f, "rb").read())
-print(h.hexdigest(), sys.argv[1])
+import json, sys
+sys.path.insert(0, ".")
+import bench                      # unit_hashes(): one hash per translation unit (source + shared headers + compile flags)
+print(json.dumps({"commit": sys.argv[1], "units": bench.unit_hashes()}))
 PY
 common="--no-cpu-baseline --no-roofline --no-f32-line --no-extra-configs"
 stats() {   # name, bench arguments
