@@ -125,11 +125,16 @@ __device__ __forceinline__ void asr_split_f16(float v, _Float16& hi, _Float16& l
 // stays one (MODE.FP16_OVFL preserves INF), where asr_split_f16 gives 65504.
 typedef float asr_f32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 asr_f16x2 __attribute__((ext_vector_type(2)));
-// ASR_DIAG_TOUCH_VGPR(n): raise the kernel's vector-register allocation to n + 1 (diagnostic builds only: how many waves of
-// which kernels share a SIMD's 512 registers is one of the variables of tools/build_hazard_variants.py)
+// ASR_TOUCH_VGPR(n): raise the kernel's vector-register allocation to at least n + 1 by naming register n once.  How many
+// waves of which kernels share a SIMD's 512 registers decides who can meet whom there: the fused
+// entry-flow kernels hold AT LEAST ASR_FUSED_MIN_VGPRS each (two waves per SIMD, one workgroup per CU), so that only
+// kernels of <= 112 registers -- none of which contains a packed-f32 instruction, csrc/isa_guard.py -- fit beside them.
+// Costs nothing: their occupancy is set by LDS.  (Also the knob of tools/build_hazard_variants.py.)
 #define ASR_DIAG_STR2(x) #x
 #define ASR_DIAG_STR(x) ASR_DIAG_STR2(x)
-#define ASR_DIAG_TOUCH_VGPR(n) asm volatile("v_mov_b32 v" ASR_DIAG_STR(n) ", 0" ::: "v" ASR_DIAG_STR(n))
+#define ASR_TOUCH_VGPR(n) asm volatile("v_mov_b32 v" ASR_DIAG_STR(n) ", 0" ::: "v" ASR_DIAG_STR(n))
+#define ASR_DIAG_TOUCH_VGPR(n) ASR_TOUCH_VGPR(n)
+#define ASR_FUSED_MIN_VGPRS 200
 // Diagnostic switches (tools/build_hazard_variants.py; never defined in the product build): ASR_DIAG_NO_SETREG leaves MODE
 // alone (the packed conversions then overflow to infinity), ASR_DIAG_SCALAR_SPLIT keeps the MODE write but splits value by
 // value with clamps like asr_split_f16.

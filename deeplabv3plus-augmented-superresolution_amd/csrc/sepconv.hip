@@ -63,6 +63,8 @@ __global__ __launch_bounds__(512) ASR_PK_F32 ASR_SEPCONV_ATTR void sepconv_fused
 #endif
 #ifdef ASR_DIAG_SEPCONV_TOP_VGPR
     ASR_DIAG_TOUCH_VGPR(ASR_DIAG_SEPCONV_TOP_VGPR);
+#else
+    ASR_TOUCH_VGPR(199);                                      // >= ASR_FUSED_MIN_VGPRS (the 64-channel instance needs only 180)
 #endif
     constexpr int QUADS = CIN / 4;                            // channel quads: 32 or 16
     constexpr int HALVES = 32 / QUADS;                        // row halves of the tile handled by different thread slots

@@ -51,6 +51,14 @@ def test_packed_f32_only_in_kernels_too_large_to_share_a_simd_with_the_fused_ker
             assert not any(guard._PK_F32.search(i) for i in insts), kern
 
 
+def test_fused_entry_flow_kernels_hold_at_least_200_registers(guard):
+    """What makes 112 the bound above: two waves of a fused entry-flow kernel leave at most 512 - 2 x 200 registers of a SIMD."""
+    v = guard.kernel_vgprs(os.path.join(PKG, "libasr_hip.so"))
+    fused = {k: n for k, n in v.items() if any(f in k for f in guard.FUSED_KERNELS)}
+    assert len(fused) == 3 and min(fused.values()) >= guard.FUSED_MIN_VGPR, fused
+    assert guard.CORESIDENT_MAX_VGPR == 512 - 2 * guard.FUSED_MIN_VGPR == 112
+
+
 def test_mode_register_is_written_only_by_the_kernels_that_split_with_saturating_conversions(guard):
     writers = guard.summary()["mode_writers"]
     assert writers, "the saturating split (asr_common.h) is expected in the fused entry-flow kernels"
