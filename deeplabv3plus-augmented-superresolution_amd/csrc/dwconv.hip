@@ -129,6 +129,34 @@ __global__ __launch_bounds__(256) void dw_stream_kernel(DwArgs p, int tiles_x) {
 // then the number of chunks per pixel; channels c .. 32 * ldy - 1 are written as zeros (the GEMM reads whole chunks).
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
+// The split of four output values into the hi / lo dwords of the A-operand line.  1 (default): the packed saturating
+// conversions of asr_common.h in a wave that has called asr_enable_f16_saturation() -- 10 - 12 vector instructions instead of
+// 24 for the four values, in kernels that are bound by VALU issue; 0: clamp + convert per value (rounds 1 - 3).  Same halves
+// for every finite input.
+#ifndef ASR_DW_PACKED_SPLIT
+#define ASR_DW_PACKED_SPLIT 1
+#endif
+typedef unsigned int dw_u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void dw_split4(const f32x4& acc, dw_u32x2& h2, dw_u32x2& l2) {
+#if ASR_DW_PACKED_SPLIT
+    unsigned int h01, h23, l01, l23;
+    asr_split4_f16_saturating_mode(acc[0], acc[1], acc[2], acc[3], h01, h23, l01, l23);
+    h2 = dw_u32x2{h01, h23};
+    l2 = dw_u32x2{l01, l23};
+#else
+    f16x4 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        _Float16 h, l;
+        asr_split_f16(acc[e], h, l);
+        hi[e] = h;
+        lo[e] = l;
+    }
+    h2 = __builtin_bit_cast(dw_u32x2, hi);
+    l2 = __builtin_bit_cast(dw_u32x2, lo);
+#endif
+}
+
 // ACT: 0 = activations from the runtime flags, 1 = pre-ReLU only (the sepconvs without depth activation), 2 = post-ReLU
 // only (with depth activation) -- at ~5 TB/s these kernels are bound by VALU issue (3 waves per SIMD, ~150 instructions
 // per output row), and a runtime flag costs a v_max + v_cndmask per loaded element instead of one v_max.
@@ -147,6 +175,9 @@ template <int R, int S, int SROWS, int PF, bool SPLIT, int ACT>
 __global__ __launch_bounds__(256) ASR_PK_F32 void dw_stream_full_kernel(DwArgs p, int tiles_x) {
     constexpr int WIN = 2 * R + 1;
     static_assert(SROWS % PF == 0, "strip length must be a multiple of the prefetch depth");
+#if ASR_DW_PACKED_SPLIT
+    if (SPLIT) asr_enable_f16_saturation();                   // dw_split4 converts with the hardware's f16 clamp
+#endif
     const int tid = threadIdx.x;
     const int c4 = tid & 15, col = tid >> 4;
     const int tx = blockIdx.x % tiles_x, cbk = blockIdx.x / tiles_x;
@@ -237,20 +268,13 @@ __global__ __launch_bounds__(256) ASR_PK_F32 void dw_stream_full_kernel(DwArgs p
             if (ACT == 2) acc = relu4(acc);
             else if (ACT == 0) acc = post_act4(acc, p.post_relu);
             if (SPLIT) {
-                f16x4 hi, lo;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    _Float16 h, l;
-                    asr_split_f16(acc[e], h, l);
-                    hi[e] = h;
-                    lo[e] = l;
-                }
                 // Lane pairs (channel quads 2j, 2j+1; c % 8 == 0) trade halves through DPP so that each lane issues ONE
                 // 16-byte store -- the even lane the 8 hi halfs of both quads, the odd lane their 8 lo halfs -- instead of
                 // two 8-byte stores per lane (which cost the split variant 15 % of the kernel's bandwidth).
-                typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+                typedef dw_u32x2 u32x2;
                 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-                const u32x2 h2 = __builtin_bit_cast(u32x2, hi), l2 = __builtin_bit_cast(u32x2, lo);
+                u32x2 h2, l2;
+                dw_split4(acc, h2, l2);
                 const bool even = (c4 & 1) == 0;
                 const u32x2 give = even ? l2 : h2;
                 u32x2 got;
@@ -303,6 +327,9 @@ struct AsppArgs {
 // exactly one chunk, ldy = chunks per pixel; c % 32 == 0.
 template <bool SPLIT>
 __global__ __launch_bounds__(ATHREADS) void aspp_dw3_phase_kernel(AsppArgs p) {
+#if ASR_DW_PACKED_SPLIT
+    if (SPLIT) asr_enable_f16_saturation();                   // dw_split4 converts with the hardware's f16 clamp
+#endif
     extern __shared__ __attribute__((aligned(16))) float lds[];  // [rows * cols + 1 zero line][ACB] floats, then int xtab[cols]
     const int tid = threadIdx.x;
     const int c4 = tid & 7, slot = tid >> 3;                     // 8 lanes x 16 bytes = one line; 32 line slots
@@ -372,17 +399,10 @@ __global__ __launch_bounds__(ATHREADS) void aspp_dw3_phase_kernel(AsppArgs p) {
             acc = post_act4(acc, p.post_relu);
             const long long pix = (long long)b * p.h * p.w_ + (long long)(py + i * g) * p.w_ + xx;
             if (SPLIT) {
-                f16x4 hi, lo;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    _Float16 h, l2;
-                    asr_split_f16(acc[e], h, l2);
-                    hi[e] = h;
-                    lo[e] = l2;
-                }
-                typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+                typedef dw_u32x2 u32x2;
                 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-                const u32x2 h2 = __builtin_bit_cast(u32x2, hi), l2 = __builtin_bit_cast(u32x2, lo);
+                u32x2 h2, l2;
+                dw_split4(acc, h2, l2);
                 const bool even = (c4 & 1) == 0;
                 const u32x2 give = even ? l2 : h2;
                 u32x2 got;

@@ -35,7 +35,8 @@ _LLVM_BIN = [os.environ.get("ASR_LLVM_BIN", ""), "/opt/rocm/lib/llvm/bin", "/opt
 
 # kernels (demangled-name substrings) that may write the MODE register: they switch the f16 overflow clamp on for their
 # saturating split (asr_common.h: asr_enable_f16_saturation)
-MODE_WRITERS = ("entry_stem_fused_kernel", "conv3x3_stem_mfma_kernel", "pw_gemm_f16x3_kernel", "sepconv_fused_kernel")
+MODE_WRITERS = ("entry_stem_fused_kernel", "conv3x3_stem_mfma_kernel", "pw_gemm_f16x3_kernel", "sepconv_fused_kernel",
+                "dw_stream_full_kernel", "aspp_dw3_phase_kernel")
 
 # the fused entry-flow kernels keep two waves of >= 200 registers on a SIMD: what fits beside them has at most this many
 FUSED_KERNELS = ("entry_stem_fused_kernel", "sepconv_fused_kernel")

@@ -112,7 +112,14 @@ class HotPath:
         """image_dev [H,W,3] float32 device; angles [N], shifts [N,2] float32 host arrays;
         gt_dev [H,W] int32 device labels (optional).  Returns dict of device masks (+ 6 IoUs)."""
         res, y, ymax = self._stage_model(image_dev, angles, shifts, profile, want_standard)
+        if profile is not None:         # the SR stage (solve, realign, thresholds, IoU counts) as one HIP-event interval
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         res = self._stage_sr(res, y, ymax, angles, self._sr_frame(image_dev, shifts), gt_dev, adam_start, sr_types)
+        if profile is not None:
+            e1.record()
+            torch.cuda.synchronize()
+            profile["_sr_stage_ms"] = profile.get("_sr_stage_ms", 0.0) + e0.elapsed_time(e1)
         return self._finish(res)
 
     def submit_image(self, image_dev, angles, shifts, gt_dev=None, adam_start=None,

@@ -53,6 +53,8 @@ OBJECTS = {
     "sepconv_v192": ("sepconv.hip", ["-DASR_DIAG_SEPCONV_TOP_VGPR=191"]),
     "sepconv_v200": ("sepconv.hip", ["-DASR_DIAG_SEPCONV_TOP_VGPR=199"]),
     "sepconv_v208": ("sepconv.hip", ["-DASR_DIAG_SEPCONV_TOP_VGPR=207"]),
+    # A/B objects (tools/ab_entry_points.py): the depthwise kernels on the clamped value-by-value split of rounds 1 - 3
+    "dwconv_clamped": ("dwconv.hip", ["-DASR_DW_PACKED_SPLIT=0"]),
     "sr_pk_v112": ("sr.hip", FP + ["-DASR_DIAG_KFWD_TOP_VGPR=111"]),
     "sr_nopk_v96": ("sr.hip", FP + B.NO_PK_F32 + ["-DASR_DIAG_KFWD_TOP_VGPR=95"]),     # the product's K_fwd, allocation raised from 64 to 96
 }
@@ -72,6 +74,7 @@ LIBS = {
     "pk_stem208": {"sr": "sr_pk", "layers": "layers_v208"},
     "pk_sepconv_pk_v216": {"sr": "sr_pk", "sepconv": "sepconv_pk_v216"},
     "pk112": {"sr": "sr_pk_v112"},
+    "dwclamped": {"dwconv": "dwconv_clamped"},
     "pk_sepconv192": {"sr": "sr_pk", "sepconv": "sepconv_v192"},
     "pk_sepconv200": {"sr": "sr_pk", "sepconv": "sepconv_v200"},
     "pk_sepconv208": {"sr": "sr_pk", "sepconv": "sepconv_v208"},
@@ -89,7 +92,8 @@ def main():
         deps = [s] + [os.path.join(CSRC, h) for h in B.HEADERS] + [os.path.abspath(__file__)]
         if B._stale(o, deps):
             extra = dict(B.SOURCES)[src]
-            extra = [f for f in extra if f not in B.NO_PK_F32 and f not in FP]
+            if src == "sr.hip":        # the sr variants state their own flags (with or without packed-f32)
+                extra = [f for f in extra if f not in B.NO_PK_F32 and f not in FP]
             cmd = [hipcc] + B.COMMON + extra + flags + ["-c", s, "-o", o]
             print(" ".join(cmd), flush=True)
             B._compile(cmd)
