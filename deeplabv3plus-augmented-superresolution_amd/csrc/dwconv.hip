@@ -133,6 +133,9 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 // conversions of asr_common.h in a wave that has called asr_enable_f16_saturation() -- 10 - 12 vector instructions instead of
 // 24 for the four values, in kernels that are bound by VALU issue; 0: clamp + convert per value (rounds 1 - 3).  Same halves
 // for every finite input.
+#ifndef ASR_DIAG_DW
+#define ASR_DIAG_DW 0                                          // ablation bits (tools/build_hazard_variants.py: dw_skip*); 0 in the product
+#endif
 #ifndef ASR_DW_PACKED_SPLIT
 #define ASR_DW_PACKED_SPLIT 1
 #endif
@@ -222,9 +225,14 @@ __global__ __launch_bounds__(256) ASR_PK_F32 void dw_stream_full_kernel(DwArgs p
 
     auto issue = [&](int iy, f32x4 (&d)[3]) {                 // three unconditional loads from a clamped row
         const float* row = xin + (long long)min(max(iy, 0), p.h_in - 1) * row_stride;
+#if ASR_DIAG_DW & 4                                             // ablation: the centre column only (one load per row instead of three)
+        d[1] = *reinterpret_cast<const f32x4*>(row + ofc);
+        d[0] = d[1]; d[2] = d[1];
+#else
         d[0] = *reinterpret_cast<const f32x4*>(row + ofl);     // (non-temporal LOADS are 20 % slower: the two neighbour
         d[1] = *reinterpret_cast<const f32x4*>(row + ofc);     //  columns are L1 hits of other lanes' centre loads)
         d[2] = *reinterpret_cast<const f32x4*>(row + ofr);
+#endif
     };
     auto enter = [&](int iy, const f32x4 (&d)[3], f32x4 (&w)[3]) {   // top / bottom zero padding + pre-activation at window entry
         // the row index is the same for the whole workgroup: a scalar branch in the (rare) padding rows, nothing otherwise
@@ -261,12 +269,22 @@ __global__ __launch_bounds__(256) ASR_PK_F32 void dw_stream_full_kernel(DwArgs p
 #pragma unroll
             for (int t = 0; t < S; ++t) issue(base0 + (r + PF) * S + WIN - S + t, q[j][t]);   // past the strip: clamped re-read, unused
             f32x4 acc = bv;
+#if ASR_DIAG_DW & 1                                             // ablation: one tap instead of nine (loads stay)
+            acc += win[R][1] * wk[4] + win[0][0] + win[2 * R][2];
+#else
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx) acc += win[ky * R][kx] * wk[ky * 3 + kx];
+#endif
             if (ACT == 2) acc = relu4(acc);
             else if (ACT == 0) acc = post_act4(acc, p.post_relu);
+#if ASR_DIAG_DW & 2                                             // ablation: f32 bytes to the split operand's address (no split, no lane trade)
+            if (SPLIT) {
+                _Float16* o = ysplit + (long long)(oy0 + r) * split_row_stride + ((c4 & 1) ? 32 - 4 : 0);
+                __builtin_nontemporal_store(acc, reinterpret_cast<f32x4*>(o));
+            } else
+#endif
             if (SPLIT) {
                 // Lane pairs (channel quads 2j, 2j+1; c % 8 == 0) trade halves through DPP so that each lane issues ONE
                 // 16-byte store -- the even lane the 8 hi halfs of both quads, the odd lane their 8 lo halfs -- instead of

@@ -230,6 +230,9 @@ __global__ __launch_bounds__(256) ASR_PK_F32 void conv3x3_stem_mfma_kernel(const
 //            kernel's lifetime: 108 MFMAs per wave and tile, no global A traffic at all.
 // The 32-channel intermediate (839 MB per 100 copies, written once and re-read nine times through L2 by the implicit
 // GEMM of the two-kernel form) never leaves the CU.
+#ifndef ASR_DIAG_STEM_SKIP
+#define ASR_DIAG_STEM_SKIP 0                                   // ablation bits of tools/build_hazard_variants.py ("stem_skip*"); 0 in the product
+#endif
 constexpr int ES_T = 16, ES_H = ES_T + 2, ES_NPIX = ES_H * ES_H, ES_GROUPS = (ES_NPIX + 31) / 32;
 // Row stride of the LDS image in lines.  Stage 2 reads, per ds_read_b128 phase of 16 lanes, 8 lines of one tile row and 8 of
 // the next; with the natural stride 18 two of the 16 land on the same bank group as two others (28 % of the LDS cycles
@@ -313,7 +316,11 @@ __global__ __launch_bounds__(512) ASR_PK_F32 void entry_stem_fused_kernel(const 
         for (int k = 0; k < 16; ++k) {
             const int iy = iy0 + (kyx[k] & 3), ix = ix0 + ((kyx[k] >> 2) & 3);
             const bool in = (kyx[k] & 16) && r.in_map && iy < h_in && ix < w_in;
+#if ASR_DIAG_STEM_SKIP & 1                                      // ablation: no image loads
+            const float v = 0.25f * (float)k;
+#else
             const float v = xin[in ? org + off[k] : 0];
+#endif
             r.a[k] = in ? v : 0.0f;
         }
         return r;
@@ -353,8 +360,12 @@ __global__ __launch_bounds__(512) ASR_PK_F32 void entry_stem_fused_kernel(const 
     for (long long tile = blockIdx.x; tile < total; tile += gridDim.x) {
         __syncthreads();                                       // the previous tile's stage 2 is done with the LDS image
         // ---- stage 1: conv1_1 (+ bias, ReLU) of the 18 x 18 halo tile -> split-f16 lines in LDS ----
+#if ASR_DIAG_STEM_SKIP & 8                                      // ablation: no stage 1 at all (stage 2 reads whatever the LDS holds)
+        if (tile < 0) finish(gather(tile, wave), T1);
+#else
         finish(gather(tile, wave), T1);
         if (two_groups) finish(gather(tile, wave + 8), T1);
+#endif
         __syncthreads();
         const int tx0 = (int)(tile % tiles_x) * ES_T;
         const long long tt = tile / tiles_x;
@@ -368,7 +379,7 @@ __global__ __launch_bounds__(512) ASR_PK_F32 void entry_stem_fused_kernel(const 
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc2[j][e] = 0.0f;
 #pragma unroll 3                                               // fully unrolled, the hoisted LDS reads spill
-        for (int tap = 0; tap < 9; ++tap) {
+        for (int tap = 0; tap < ((ASR_DIAG_STEM_SKIP & 2) ? 1 : 9); ++tap) {      // (ablation bit 2: one tap instead of nine)
             const int ky = (tap * 11) >> 5;                    // tap / 3 for tap < 9
             const int tp = (yy + ky) * ES_LS + xx + (tap - 3 * ky);
             const char* const line = T1 + tp * 128;
@@ -394,7 +405,7 @@ __global__ __launch_bounds__(512) ASR_PK_F32 void entry_stem_fused_kernel(const 
         for (int e = 0; e < 16; ++e) {
             const int r = 32 * wave + (e & 3) + 8 * (e >> 2) + 4 * hh;       // pixel of accumulator row e
             const int oy = ty0 + (r >> 4), ox = tx0 + (r & 15);
-            if (oy < h1 && ox < w1d) {
+            if (oy < h1 && ox < w1d && !((ASR_DIAG_STEM_SKIP & 4) && acc2[0][e] != 12345.678f)) {      // (ablation bit 4: no stores)
                 float* const q = ybase + ((long long)oy * w1d + ox) * ldy;
                 q[0] = fmaxf(acc2[0][e] + b2v0, 0.0f);
                 q[32] = fmaxf(acc2[1][e] + b2v1, 0.0f);

@@ -55,6 +55,18 @@ OBJECTS = {
     "sepconv_v208": ("sepconv.hip", ["-DASR_DIAG_SEPCONV_TOP_VGPR=207"]),
     # A/B objects (tools/ab_entry_points.py): the depthwise kernels on the clamped value-by-value split of rounds 1 - 3
     "dwconv_clamped": ("dwconv.hip", ["-DASR_DW_PACKED_SPLIT=0"]),
+    # ablations of the fused stem (tools/bench_stem_ablation.py): what its 19 K cycles per tile are made of
+    "layers_skip1": ("layers.hip", ["-DASR_DIAG_STEM_SKIP=1"]),      # no image loads
+    "layers_skip2": ("layers.hip", ["-DASR_DIAG_STEM_SKIP=2"]),      # stage 2 with one tap instead of nine
+    "layers_skip4": ("layers.hip", ["-DASR_DIAG_STEM_SKIP=4"]),      # no output stores
+    "layers_skip8": ("layers.hip", ["-DASR_DIAG_STEM_SKIP=8"]),      # no stage 1
+    "layers_skip12": ("layers.hip", ["-DASR_DIAG_STEM_SKIP=12"]),    # stage 2 alone, no stores
+    "layers_skip6": ("layers.hip", ["-DASR_DIAG_STEM_SKIP=6"]),      # stage 1 alone
+    # ablations of the streaming depthwise kernel (tools/bench_step_variants.py)
+    "dwconv_skip1": ("dwconv.hip", ["-DASR_DIAG_DW=1"]),      # one tap of nine
+    "dwconv_skip2": ("dwconv.hip", ["-DASR_DIAG_DW=2"]),      # f32 store instead of split + lane trade
+    "dwconv_skip4": ("dwconv.hip", ["-DASR_DIAG_DW=4"]),      # one load per row instead of three
+    "dwconv_skip7": ("dwconv.hip", ["-DASR_DIAG_DW=7"]),      # all three: a copy with the kernel's skeleton
     "sr_pk_v112": ("sr.hip", FP + ["-DASR_DIAG_KFWD_TOP_VGPR=111"]),
     "sr_nopk_v96": ("sr.hip", FP + B.NO_PK_F32 + ["-DASR_DIAG_KFWD_TOP_VGPR=95"]),     # the product's K_fwd, allocation raised from 64 to 96
 }
@@ -75,6 +87,10 @@ LIBS = {
     "pk_sepconv_pk_v216": {"sr": "sr_pk", "sepconv": "sepconv_pk_v216"},
     "pk112": {"sr": "sr_pk_v112"},
     "dwclamped": {"dwconv": "dwconv_clamped"},
+    "dw_skip1": {"dwconv": "dwconv_skip1"}, "dw_skip2": {"dwconv": "dwconv_skip2"}, "dw_skip4": {"dwconv": "dwconv_skip4"},
+    "dw_skip7": {"dwconv": "dwconv_skip7"},
+    "stem_skip1": {"layers": "layers_skip1"}, "stem_skip2": {"layers": "layers_skip2"}, "stem_skip4": {"layers": "layers_skip4"},
+    "stem_skip8": {"layers": "layers_skip8"}, "stem_skip12": {"layers": "layers_skip12"}, "stem_skip6": {"layers": "layers_skip6"},
     "pk_sepconv192": {"sr": "sr_pk", "sepconv": "sepconv_v192"},
     "pk_sepconv200": {"sr": "sr_pk", "sepconv": "sepconv_v200"},
     "pk_sepconv208": {"sr": "sr_pk", "sepconv": "sepconv_v208"},
