@@ -38,7 +38,14 @@ class DeeplabV3Plus:
         if backbone == "mobilenet":
             OS = 8                                     # model.py:53-55: OS is set to 8 for the mobilenet backbone
         if input_tensor is not None:
-            raise NotImplementedError("input_tensor (Keras graph splicing) has no meaning here")
+            # model.py:57-62,114-116: the reference wires an existing Keras tensor in as the model's input.  There is no
+            # graph to splice into here; what carries over is the tensor's static shape, which replaces input_shape
+            # (anything with a .shape of rank 3 or 4 -- a Keras tensor, an ndarray, a torch tensor).
+            shape = tuple(int(d) for d in tuple(input_tensor.shape)[-3:])
+            if len(shape) != 3 or any(d <= 0 for d in shape):
+                raise ValueError(f"input_tensor must have a static [.., H, W, C] shape, got {tuple(input_tensor.shape)}")
+            input_shape = shape
+        self.input_tensor = input_tensor
         self.weights = weights
         self.input_shape = tuple(input_shape)
         self.classes = classes

@@ -345,9 +345,9 @@ def test_presplit_sepconv_matches_the_f32_handoff(dev, c, n, hw, stride, rate):
 def test_presplit_gemm_persistent_walk_is_bit_identical_to_one_tile_per_workgroup(dev, k, n, relu):
     """Rows are independent: one launch over all rows must equal, bit for bit, launches over row blocks of <= 256 tiles --
     ragged M, the padded last N-tile of 728, every activation mode -- and sit within the f32-grade bound of the float64
-    product.  (Written for the persistent walk of the ring GEMM, pw_gemm_f16x3_pre_ring_persist_kernel, which takes launches
-    of more than 256 tiles in the experiment build -DASR_PERSISTENT_WALK=1 and passes this test; the product build runs
-    one tile per workgroup on both sides: DESIGN.md 4.1.)"""
+    product.  The whole launch runs the persistent walk of the ring GEMM (pw_gemm_f16x3_pre_ring_persist_kernel: more tiles
+    than CUs, no residual -- the product path since round 4), the row blocks run pw_gemm_f16x3_pre_ring_kernel, one tile
+    per workgroup: DESIGN.md 4.1.)"""
     from asr_amd import ops
     rng = np.random.default_rng(77)
     m = 70000 + 37                                             # 274 row tiles, the last one ragged

@@ -19,6 +19,10 @@ def test_deeplab_constructor_validation_matches_reference():
     assert DeeplabV3Plus(OS=8).OS == 8
     with pytest.raises(ValueError, match="OS"):
         DeeplabV3Plus(OS=32)
+    # model.py:57-62: an input tensor replaces input_shape (its static shape is what carries over)
+    assert DeeplabV3Plus(input_tensor=np.zeros((1, 256, 384, 3), np.float32)).input_shape == (256, 384, 3)
+    with pytest.raises(ValueError, match="input_tensor"):
+        DeeplabV3Plus(input_tensor=np.zeros((3,), np.float32))
     m = DeeplabV3Plus(input_shape=(512, 512, 3), classes=21, OS=16, last_activation=None, load_weights=True,
                       backbone="xception")
     with pytest.raises(ValueError, match="only_DCNN_output"):
