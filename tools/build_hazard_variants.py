@@ -89,6 +89,10 @@ LIBS = {
     "dwclamped": {"dwconv": "dwconv_clamped"},
     "dw_skip1": {"dwconv": "dwconv_skip1"}, "dw_skip2": {"dwconv": "dwconv_skip2"}, "dw_skip4": {"dwconv": "dwconv_skip4"},
     "dw_skip7": {"dwconv": "dwconv_skip7"},
+    # fourth matrix: which PART of the stem makes it an aggressor (victim = K_fwd with packed-f32)
+    "pk_stem_skip1": {"sr": "sr_pk", "layers": "layers_skip1"}, "pk_stem_skip2": {"sr": "sr_pk", "layers": "layers_skip2"},
+    "pk_stem_skip4": {"sr": "sr_pk", "layers": "layers_skip4"}, "pk_stem_skip8": {"sr": "sr_pk", "layers": "layers_skip8"},
+    "pk_stem_skip12": {"sr": "sr_pk", "layers": "layers_skip12"}, "pk_stem_skip6": {"sr": "sr_pk", "layers": "layers_skip6"},
     "stem_skip1": {"layers": "layers_skip1"}, "stem_skip2": {"layers": "layers_skip2"}, "stem_skip4": {"layers": "layers_skip4"},
     "stem_skip8": {"layers": "layers_skip8"}, "stem_skip12": {"layers": "layers_skip12"}, "stem_skip6": {"layers": "layers_skip6"},
     "pk_sepconv192": {"sr": "sr_pk", "sepconv": "sepconv_v192"},

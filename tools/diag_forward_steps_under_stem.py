@@ -8,7 +8,12 @@ plan launch by launch and, for each launch, compares the output written quietly 
 (and fused separable convs) are replayed on another stream -- bit for bit.
 
     python tools/diag_forward_steps_under_stem.py [trials per launch, default 3] [copies, default 100]
+    AGGR=synthetic:<mode>:<registers>:<iterations> python tools/diag_forward_steps_under_stem.py ...
+        the aggressor is a synthetic one-ingredient kernel instead (tools/hazard_aggressors.hip; mode 1 = a bare
+        v_mfma_f32_16x16x32_f16 loop, the strongest aggressor found: with 128 registers per wave it leaves room for a
+        co-resident wave of up to 256 registers, i.e. for every kernel of the forward pass)
 """
+import os
 import sys
 import torch
 sys.path.insert(0, "/root/repo")
@@ -30,6 +35,31 @@ AGGR = ("asr_entry_stem_f16x3", "asr_sepconv_fused_f16x3")
 aggr_steps = [s for s in aggr["steps"] if s[0] in AGGR]
 print("aggressor launches:", [s[5] or s[0] for s in aggr_steps], flush=True)
 sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+
+
+_syn = None
+if os.environ.get("AGGR", "").startswith("synthetic:"):
+    import ctypes
+    import subprocess
+    so = "/tmp/libhazard_aggressors.so"
+    subprocess.check_call(["hipcc", "-O2", "--offload-arch=gfx950", "-shared", "-fPIC",
+                           os.path.join(os.path.dirname(os.path.abspath(__file__)), "hazard_aggressors.hip"), "-o", so],
+                          stderr=subprocess.DEVNULL)
+    _fn = ctypes.CDLL(so).hazard_aggressor
+    _fn.restype, _fn.argtypes = ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    _m, _mode, _regs, _iters = os.environ["AGGR"].split(":")
+    _syn = (int(_mode), int(_regs), int(_iters))
+    print("synthetic aggressor (mode, registers, iterations):", _syn, flush=True)
+
+
+def launch_aggressors(stream):
+    if _syn is None:
+        for a in aggr_steps:
+            launch(a, stream)
+        return
+    with torch.cuda.stream(stream):
+        rc = _fn(_syn[0], _syn[1], _syn[2], _lib.stream_ptr())
+    assert rc == 0, rc
 
 
 def launch(step, stream):
@@ -60,8 +90,7 @@ for idx, (step, out) in enumerate(zip(victim["steps"], victim["outs"])):
     moved = 0
     worst = 0.0
     for t in range(trials):
-        for a in aggr_steps:
-            launch(a, sa)
+        launch_aggressors(sa)
         launch(step, sb)
         torch.cuda.synchronize()
         if not torch.equal(out.t, quiet):

@@ -66,9 +66,28 @@ def one_solve():
     return x0, st["ws"]
 
 
+_synthetic = None
+
+
 def replay(kind, times):
-    """kind: a plan kind ("conv" = the stem launch), or "name:<entry point>" (every launch of that entry point)."""
+    """kind: a plan kind ("conv" = the stem launch), "name:<entry point>" (every launch of that entry point), or
+    "synthetic:<mode>:<registers>:<iterations>" (tools/hazard_aggressors.hip, built into /tmp on first use)."""
+    global _synthetic
     s = _lib.stream_ptr()
+    if kind.startswith("synthetic:"):
+        if _synthetic is None:
+            import ctypes, subprocess
+            so = "/tmp/libhazard_aggressors.so"
+            subprocess.check_call(["hipcc", "-O2", "--offload-arch=gfx950", "-shared", "-fPIC",
+                                   os.path.join(os.path.dirname(os.path.abspath(__file__)), "hazard_aggressors.hip"), "-o", so],
+                                  stderr=subprocess.DEVNULL)
+            _synthetic = ctypes.CDLL(so).hazard_aggressor
+            _synthetic.restype, _synthetic.argtypes = ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+        _m, mode, regs, iters = kind.split(":")
+        for _ in range(times):
+            rc = _synthetic(int(mode), int(regs), int(iters), s)
+            assert rc == 0, rc
+        return
     for _ in range(times):
         for name, args, k, *_ in plan["steps"]:
             if k == kind or kind == "name:" + name:
@@ -107,7 +126,7 @@ def describe(name, a, q):
 
 
 # DIAG_REPLAY="conv:6" (default) | "name:asr_sepconv_fused_f16x3:3" | "name:asr_pwconv_mfma_f16x3:1" ...: what runs on the other stream
-_spec = os.environ.get("DIAG_REPLAY", "conv:6").rsplit(":", 1)
+_spec = os.environ.get("DIAG_REPLAY", "conv:6").rsplit(":", 1)      # "<kind>:<replays>"
 print("library:", os.environ.get("ASR_LIB", "(product)"), "| replay:", _spec, "| launches per replay:",
       sum(1 for st in plan["steps"] if st[2] == _spec[0] or _spec[0] == "name:" + st[0]), flush=True)
 for kind, reps in ((_spec[0], int(_spec[1])),):

@@ -22,18 +22,37 @@
 
 typedef float f2 __attribute__((ext_vector_type(2)));
 
-// bad[form * 64 + lane]; forms: 0 pk_mul low regs, 1 pk_mul high regs, 2 pk_add high, 3 pk_fma high, 4 unpacked mul high (control)
+// bad[form * 64 + lane]; NFORMS instruction forms, each checked lane by lane against unpacked arithmetic written out in asm:
+//   0 pk_mul low registers      1 pk_mul high registers     2 pk_add high        3 pk_fma high       4 unpacked v_mul (control)
+//   5 pk_mul IN PLACE (dst = src0)                          6 pk_mul in place with the halves of src0 swapped (op_sel:[1,0] op_sel_hi:[0,1])
+//   7 pk_add in place with neg_lo / neg_hi on src1          8 pk_mul with op_sel_hi:[1,0] (low half of src1 for both)
+//   9 a chain of four dependent in-place packed ops (mul, add, mul swapped, add neg)
 // alloc_all[base granule 0..63], alloc_bad[base granule]: histogram of VGPR_BASE (units of 8 registers) over all / failing waves
+constexpr int NFORMS = 10;
+// LOADS: eight 8-byte global loads per lane are in flight (into v60..v75, not otherwise used) while the packed ops execute --
+// K_fwd of the SR solver issues its 18 tap loads and computes the next coordinates behind them.
+template <bool LOADS>
 __global__ __launch_bounds__(256) void victim(const float* __restrict__ src, unsigned* __restrict__ bad, unsigned* __restrict__ alloc_all,
                                               unsigned* __restrict__ alloc_bad, unsigned* __restrict__ first_bad, int iters) {
     const int lane = threadIdx.x & 63;
     f2 a = {src[lane] + 0.01f * (blockIdx.x & 63), src[64 + lane]}, b = {src[128 + lane], src[192 + lane] - 0.003f * (blockIdx.x & 31)};
-    unsigned nbad[5] = {0, 0, 0, 0, 0};
+    unsigned nbad[NFORMS];
+#pragma unroll
+    for (int f = 0; f < NFORMS; ++f) nbad[f] = 0;
     for (int it = 0; it < iters; ++it) {
-        float lx, ly, hx, hy, ax, ay, fx, fy, ux, uy;
+        float r[NFORMS][2];
+        if (LOADS) {
+            const float* q = src + ((lane * 2 + it * 64) & 255);
+            asm volatile(
+                "global_load_dwordx2 v[60:61], %0, off\n global_load_dwordx2 v[62:63], %0, off offset:256\n"
+                "global_load_dwordx2 v[64:65], %0, off offset:512\n global_load_dwordx2 v[66:67], %0, off offset:768\n"
+                "global_load_dwordx2 v[68:69], %0, off offset:8\n global_load_dwordx2 v[70:71], %0, off offset:264\n"
+                "global_load_dwordx2 v[72:73], %0, off offset:520\n global_load_dwordx2 v[74:75], %0, off offset:776\n"
+                :: "v"(q) : "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "memory");
+        }
         asm volatile(
-            "v_mov_b32 v8, %10\n v_mov_b32 v9, %11\n v_mov_b32 v10, %12\n v_mov_b32 v11, %13\n"
-            "v_mov_b32 v84, %10\n v_mov_b32 v85, %11\n v_mov_b32 v86, %12\n v_mov_b32 v87, %13\n"
+            "v_mov_b32 v8, %20\n v_mov_b32 v9, %21\n v_mov_b32 v10, %22\n v_mov_b32 v11, %23\n"
+            "v_mov_b32 v84, %20\n v_mov_b32 v85, %21\n v_mov_b32 v86, %22\n v_mov_b32 v87, %23\n"
             "v_pk_mul_f32 v[12:13], v[8:9], v[10:11]\n"
             "v_pk_mul_f32 v[88:89], v[84:85], v[86:87]\n"
             "v_pk_add_f32 v[90:91], v[84:85], v[86:87]\n"
@@ -41,27 +60,64 @@ __global__ __launch_bounds__(256) void victim(const float* __restrict__ src, uns
             "v_mul_f32 v94, v84, v86\n v_mul_f32 v95, v85, v87\n"
             "v_mov_b32 %0, v12\n v_mov_b32 %1, v13\n v_mov_b32 %2, v88\n v_mov_b32 %3, v89\n v_mov_b32 %4, v90\n v_mov_b32 %5, v91\n"
             "v_mov_b32 %6, v92\n v_mov_b32 %7, v93\n v_mov_b32 %8, v94\n v_mov_b32 %9, v95\n"
-            : "=&v"(lx), "=&v"(ly), "=&v"(hx), "=&v"(hy), "=&v"(ax), "=&v"(ay), "=&v"(fx), "=&v"(fy), "=&v"(ux), "=&v"(uy)
+            // 5: in place
+            "v_mov_b32 v88, v84\n v_mov_b32 v89, v85\n"
+            "v_pk_mul_f32 v[88:89], v[88:89], v[86:87]\n"
+            "v_mov_b32 %10, v88\n v_mov_b32 %11, v89\n"
+            // 6: in place, halves of src0 swapped
+            "v_mov_b32 v90, v84\n v_mov_b32 v91, v85\n"
+            "v_pk_mul_f32 v[90:91], v[90:91], v[86:87] op_sel:[1,0] op_sel_hi:[0,1]\n"
+            "v_mov_b32 %12, v90\n v_mov_b32 %13, v91\n"
+            // 7: in place add with negated src1
+            "v_mov_b32 v92, v84\n v_mov_b32 v93, v85\n"
+            "v_pk_add_f32 v[92:93], v[92:93], v[86:87] neg_lo:[0,1] neg_hi:[0,1]\n"
+            "v_mov_b32 %14, v92\n v_mov_b32 %15, v93\n"
+            // 8: low half of src1 for both results
+            "v_pk_mul_f32 v[94:95], v[84:85], v[86:87] op_sel_hi:[1,0]\n"
+            "v_mov_b32 %16, v94\n v_mov_b32 %17, v95\n"
+            // 9: chain of four dependent in-place ops
+            "v_mov_b32 v88, v84\n v_mov_b32 v89, v85\n"
+            "v_pk_mul_f32 v[88:89], v[88:89], v[86:87]\n"
+            "v_pk_add_f32 v[88:89], v[88:89], v[84:85]\n"
+            "v_pk_mul_f32 v[88:89], v[88:89], v[86:87] op_sel:[1,0] op_sel_hi:[0,1]\n"
+            "v_pk_add_f32 v[88:89], v[88:89], v[86:87] neg_lo:[0,1] neg_hi:[0,1]\n"
+            "v_mov_b32 %18, v88\n v_mov_b32 %19, v89\n"
+            : "=&v"(r[0][0]), "=&v"(r[0][1]), "=&v"(r[1][0]), "=&v"(r[1][1]), "=&v"(r[2][0]), "=&v"(r[2][1]), "=&v"(r[3][0]), "=&v"(r[3][1]),
+              "=&v"(r[4][0]), "=&v"(r[4][1]), "=&v"(r[5][0]), "=&v"(r[5][1]), "=&v"(r[6][0]), "=&v"(r[6][1]), "=&v"(r[7][0]), "=&v"(r[7][1]),
+              "=&v"(r[8][0]), "=&v"(r[8][1]), "=&v"(r[9][0]), "=&v"(r[9][1])
             : "v"(a.x), "v"(a.y), "v"(b.x), "v"(b.y)
-            : "v8", "v9", "v10", "v11", "v12", "v13", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95");
-        float mx, my, sx, sy, qx, qy;                           // the unpacked arithmetic, written out so that the compiler cannot pair it
-        asm volatile("v_mul_f32 %0, %1, %2" : "=v"(mx) : "v"(a.x), "v"(b.x));
-        asm volatile("v_mul_f32 %0, %1, %2" : "=v"(my) : "v"(a.y), "v"(b.y));
-        asm volatile("v_add_f32 %0, %1, %2" : "=v"(sx) : "v"(a.x), "v"(b.x));
-        asm volatile("v_add_f32 %0, %1, %2" : "=v"(sy) : "v"(a.y), "v"(b.y));
-        asm volatile("v_fma_f32 %0, %1, %2, %1" : "=v"(qx) : "v"(a.x), "v"(b.x));
-        asm volatile("v_fma_f32 %0, %1, %2, %1" : "=v"(qy) : "v"(a.y), "v"(b.y));
-        nbad[0] += (__float_as_int(lx) != __float_as_int(mx)) | (__float_as_int(ly) != __float_as_int(my));
-        nbad[1] += (__float_as_int(hx) != __float_as_int(mx)) | (__float_as_int(hy) != __float_as_int(my));
-        nbad[2] += (__float_as_int(ax) != __float_as_int(sx)) | (__float_as_int(ay) != __float_as_int(sy));
-        nbad[3] += (__float_as_int(fx) != __float_as_int(qx)) | (__float_as_int(fy) != __float_as_int(qy));
-        nbad[4] += (__float_as_int(ux) != __float_as_int(mx)) | (__float_as_int(uy) != __float_as_int(my));
+            : "v8", "v9", "v10", "v11", "v12", "v13", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95",
+              "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75");   // (loads may be landing there)
+        if (LOADS) asm volatile("s_waitcnt vmcnt(0)" ::: "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "memory");
+        // the unpacked arithmetic, written out so that the compiler cannot pair it
+        auto mul = [](float x, float y) { float z; asm volatile("v_mul_f32 %0, %1, %2" : "=v"(z) : "v"(x), "v"(y)); return z; };
+        auto add = [](float x, float y) { float z; asm volatile("v_add_f32 %0, %1, %2" : "=v"(z) : "v"(x), "v"(y)); return z; };
+        auto sub = [](float x, float y) { float z; asm volatile("v_sub_f32 %0, %1, %2" : "=v"(z) : "v"(x), "v"(y)); return z; };
+        auto fma = [](float x, float y, float w) { float z; asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(z) : "v"(x), "v"(y), "v"(w)); return z; };
+        float e[NFORMS][2];
+        e[0][0] = mul(a.x, b.x); e[0][1] = mul(a.y, b.y);
+        e[1][0] = e[0][0]; e[1][1] = e[0][1];
+        e[2][0] = add(a.x, b.x); e[2][1] = add(a.y, b.y);
+        e[3][0] = fma(a.x, b.x, a.x); e[3][1] = fma(a.y, b.y, a.y);
+        e[4][0] = e[0][0]; e[4][1] = e[0][1];
+        e[5][0] = e[0][0]; e[5][1] = e[0][1];
+        e[6][0] = mul(a.y, b.x); e[6][1] = mul(a.x, b.y);
+        e[7][0] = sub(a.x, b.x); e[7][1] = sub(a.y, b.y);
+        e[8][0] = e[0][0]; e[8][1] = mul(a.y, b.x);
+        {
+            float c0 = add(e[0][0], a.x), c1 = add(e[0][1], a.y);         // after mul, add
+            float d0 = mul(c1, b.x), d1 = mul(c0, b.y);                   // swapped mul
+            e[9][0] = sub(d0, b.x); e[9][1] = sub(d1, b.y);
+        }
+#pragma unroll
+        for (int f = 0; f < NFORMS; ++f)
+            nbad[f] += (__float_as_int(r[f][0]) != __float_as_int(e[f][0])) | (__float_as_int(r[f][1]) != __float_as_int(e[f][1]));
         a.x += 0.5f;
         b.y -= 0.25f;
     }
     unsigned any = 0;
 #pragma unroll
-    for (int f = 0; f < 5; ++f) {
+    for (int f = 0; f < NFORMS; ++f) {
         if (nbad[f]) atomicAdd(&bad[f * 64 + lane], nbad[f]);
         any |= nbad[f];
     }
@@ -166,8 +222,8 @@ int main(int argc, char** argv) {
     CK(hipStreamCreateWithFlags(&sa, hipStreamNonBlocking));
     CK(hipStreamCreateWithFlags(&sb, hipStreamNonBlocking));
     float *src, *sink;
-    unsigned* stats;                                            // bad[320] | alloc_all[64] | alloc_bad[64] | first_bad[18]
-    CK(hipMalloc(&src, 512 * 4)); CK(hipMalloc(&sink, (size_t)4 << 22)); CK(hipMalloc(&stats, 512 * 4));
+    unsigned* stats;                                            // bad[NFORMS * 64] | alloc_all[64] | alloc_bad[64] | first_bad[18]
+    CK(hipMalloc(&src, 512 * 4)); CK(hipMalloc(&sink, (size_t)4 << 22)); CK(hipMalloc(&stats, 1024 * 4));
     std::vector<float> hs(512);
     for (int i = 0; i < 512; ++i) hs[i] = 0.0137f * i - 1.3f;
     CK(hipMemcpy(src, hs.data(), 2048, hipMemcpyHostToDevice));
@@ -178,19 +234,15 @@ int main(int argc, char** argv) {
         {launch_aggr<200, 0>, 200, 400000, "v_fma only"},
         {launch_aggr<200, 1>, 200, 800000, "v_mfma_f32_16x16x32_f16"},
         {launch_aggr<200, 2>, 200, 400000, "v_mfma_f32_32x32x16_f16"},
-        {launch_aggr<200, 3>, 200, 30000, "LDS 16-byte writes + reads"},
-        {launch_aggr<200, 4>, 200, 200000, "DPP row shifts"},
-        {launch_aggr<200, 5>, 200, 200000, "v_permlane16_swap"},
-        {launch_aggr<200, 6>, 200, 30000, "global 16-byte loads + stores"},
-        {launch_aggr<200, 7>, 200, 100000, "packed saturating split (FP16_OVFL)"},
-        {launch_aggr<200, 8>, 200, 60000, "all of them"},
-        {launch_aggr<216, 8>, 216, 20000, "all of them (victims cannot co-reside)"},
-        {launch_aggr<160, 8>, 160, 20000, "all of them"},
+        {launch_aggr<200, 8>, 200, 60000, "all ingredients"},
+        {launch_aggr<216, 1>, 216, 800000, "v_mfma_f32_16x16x32_f16 (victims cannot co-reside)"},
     };
     const int naggr = sizeof(aggr) / sizeof(aggr[0]);
-    const char* forms[5] = {"pk_mul v8..", "pk_mul v84..", "pk_add v84..", "pk_fma v84..", "v_mul v84.. (unpacked)"};
+    const char* forms[NFORMS] = {"pk_mul v8..", "pk_mul v84..", "pk_add v84..", "pk_fma v84..", "v_mul v84.. (unpacked)", "pk_mul in place", "pk_mul in place, src0 halves swapped",
+                                 "pk_add in place, neg src1", "pk_mul op_sel_hi:[1,0]", "chain of 4 in-place packed ops"};
+    for (int with_loads = 0; with_loads < 2; ++with_loads)
     for (int m = -1; m < naggr; ++m) {
-        CK(hipMemset(stats, 0, 512 * 4));
+        CK(hipMemset(stats, 0, 1024 * 4));
         hipEvent_t e0, e1, v0, v1;
         CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1)); CK(hipEventCreate(&v0)); CK(hipEventCreate(&v1));
         float ms_a = 0.f, ms_v = 0.f;
@@ -201,28 +253,32 @@ int main(int argc, char** argv) {
                 CK(hipEventRecord(e1, sa));
             }
             CK(hipEventRecord(v0, sb));
-            for (int k = 0; k < 8; ++k)
-                hipLaunchKernelGGL(victim, dim3(vgrid), dim3(256), 0, sb, src, stats, stats + 320, stats + 384, stats + 448, viters);
+            for (int k = 0; k < 8; ++k) {
+                if (with_loads) hipLaunchKernelGGL(victim<true>, dim3(vgrid), dim3(256), 0, sb, src, stats, stats + NFORMS * 64, stats + NFORMS * 64 + 64, stats + NFORMS * 64 + 128, viters);
+                else hipLaunchKernelGGL(victim<false>, dim3(vgrid), dim3(256), 0, sb, src, stats, stats + NFORMS * 64, stats + NFORMS * 64 + 64, stats + NFORMS * 64 + 128, viters);
+            }
             CK(hipEventRecord(v1, sb));
             CK(hipGetLastError());
             CK(hipDeviceSynchronize());
             if (m >= 0) CK(hipEventElapsedTime(&ms_a, e0, e1));
             CK(hipEventElapsedTime(&ms_v, v0, v1));
         }
-        unsigned h[512];
-        CK(hipMemcpy(h, stats, 2048, hipMemcpyDeviceToHost));
+        unsigned h[1024];
+        CK(hipMemcpy(h, stats, 4096, hipMemcpyDeviceToHost));
+        const int A0 = NFORMS * 64, B0 = A0 + 64, F0 = A0 + 128;
+        printf("[victim %s loads in flight] ", with_loads ? "WITH" : "without");
         if (m < 0) printf("no aggressor (victims %.2f ms per 8 launches):\n", ms_v);
         else printf("aggressor: %s, %d registers per wave (%.2f ms per launch; victims %.2f ms per 8 launches):\n", aggr[m].what, aggr[m].nv, ms_a, ms_v);
-        for (int f = 0; f < 5; ++f) {
+        for (int f = 0; f < NFORMS; ++f) {
             unsigned long long tot = 0; int lo = 64, hi = -1;
             for (int l = 0; l < 64; ++l) if (h[f * 64 + l]) { tot += h[f * 64 + l]; lo = l < lo ? l : lo; hi = l > hi ? l : hi; }
-            if (tot) printf("    %-24s %llu mismatching results, lanes %d..%d\n", forms[f], tot, lo, hi);
-            else printf("    %-24s 0\n", forms[f]);
+            if (tot) printf("    %-38s %llu mismatching results, lanes %d..%d\n", forms[f], tot, lo, hi);
+            else printf("    %-38s 0\n", forms[f]);
         }
         printf("    victim waves by VGPR base (registers: waves [failing]):");
-        for (int g = 0; g < 64; ++g) if (h[320 + g]) printf(" %d: %u [%u]", g * 8, h[320 + g], h[384 + g]);
+        for (int g = 0; g < 64; ++g) if (h[A0 + g]) printf(" %d: %u [%u]", g * 8, h[A0 + g], h[B0 + g]);
         printf("\n");
-        for (unsigned k = 0; k < 8 && k < h[449]; ++k) printf("    failing wave: GPR_ALLOC 0x%08x HW_ID 0x%08x\n", h[450 + 2 * k], h[451 + 2 * k]);
+        for (unsigned k = 0; k < 8 && k < h[F0 + 1]; ++k) printf("    failing wave: GPR_ALLOC 0x%08x HW_ID 0x%08x\n", h[F0 + 2 + 2 * k], h[F0 + 3 + 2 * k]);
         fflush(stdout);
     }
     return 0;
