@@ -83,6 +83,32 @@ __device__ __forceinline__ void sr_map_affine(const AsrTf8& t, float x, float y,
     iy = t.b0 * x + t.b1 * y + t.b2;
 }
 
+#ifdef ASR_DIAG_KFWD_CHECK
+// Diagnostic build only (tools/build_hazard_variants.py "kfwd_check"): K_fwd re-derives every intermediate of its fast path with
+// UNPACKED arithmetic written out in asm (v_mul_f32 / v_add_f32 / v_sub_f32 never went wrong) and counts, stage by stage, where
+// the compiler's (packed) code disagrees -- which of its packed-f32 sequences fails beside co-resident MFMA waves.
+//   counters: 0 map ix   1 map iy   2 bilinear (weights / blend)   3 translate blend Tq   4 final D   5 waves with any mismatch
+//             8 + lane (64): mismatching lanes   80 + 4 * a + c... (9): which of the 3 x 3 rotation samples (map stage)
+//   records (first 16 mismatches): stage, lane, inputs, got, expected
+__device__ unsigned g_kfwd_cnt[128];
+__device__ float g_kfwd_rec[16][12];
+__device__ __forceinline__ float dg_mul(float x, float y) { float z; asm volatile("v_mul_f32 %0, %1, %2" : "=v"(z) : "v"(x), "v"(y)); return z; }
+__device__ __forceinline__ float dg_add(float x, float y) { float z; asm volatile("v_add_f32 %0, %1, %2" : "=v"(z) : "v"(x), "v"(y)); return z; }
+__device__ __forceinline__ float dg_sub(float x, float y) { float z; asm volatile("v_sub_f32 %0, %1, %2" : "=v"(z) : "v"(x), "v"(y)); return z; }
+__device__ __forceinline__ bool dg_ne(float a, float b) { return __float_as_int(a) != __float_as_int(b); }
+__device__ __forceinline__ void dg_record(int stage, float i0, float i1, float i2, float i3, float i4, float i5, float got, float want) {
+    atomicAdd(&g_kfwd_cnt[stage], 1u);
+    atomicAdd(&g_kfwd_cnt[8 + ((threadIdx.y * kTileX + threadIdx.x) & 63)], 1u);
+    const unsigned k = atomicAdd(&g_kfwd_cnt[7], 1u);
+    if (k < 16) {
+        float* r = g_kfwd_rec[k];
+        r[0] = (float)stage; r[1] = (float)((threadIdx.y * kTileX + threadIdx.x) & 63);
+        r[2] = i0; r[3] = i1; r[4] = i2; r[5] = i3; r[6] = i4; r[7] = i5; r[8] = got; r[9] = want;
+        r[10] = (float)blockIdx.z; r[11] = (float)(blockIdx.y * 1000 + blockIdx.x);
+    }
+}
+#endif
+
 // ---- K_fwd --------------------------------------------------------------------------------
 // One thread per LR residual element (b, n, i, j).  BORDERED: x is the solver's zero-bordered copy [batch, H+4, W+64].
 #ifdef ASR_DIAG_KFWD_MAX_VGPR
@@ -154,6 +180,24 @@ __global__ __launch_bounds__(256) ASR_KFWD_ATTR void sr_forward_residual_kernel(
                     sr_map_affine(tr, (float)xr, (float)yr, ix, iy);
                     const float v = sr_bilinear_bordered(img, WP, H, W, ix, iy);
                     rv[a][c] = ((yr >= 0) & (yr < H) & (xr >= 0) & (xr < W)) ? v : 0.0f;
+#ifdef ASR_DIAG_KFWD_CHECK
+                    {
+                        const float fx = (float)xr, fy = (float)yr;
+                        const float ex = dg_add(dg_add(dg_mul(tr.a0, fx), dg_mul(tr.a1, fy)), tr.a2);
+                        const float ey = dg_add(dg_add(dg_mul(tr.b0, fx), dg_mul(tr.b1, fy)), tr.b2);
+                        if (dg_ne(ix, ex)) { dg_record(0, fx, fy, tr.a0, tr.a1, tr.a2, (float)(3 * a + c), ix, ex); atomicAdd(&g_kfwd_cnt[80 + 3 * a + c], 1u); }
+                        if (dg_ne(iy, ey)) { dg_record(1, fx, fy, tr.b0, tr.b1, tr.b2, (float)(3 * a + c), iy, ey); atomicAdd(&g_kfwd_cnt[80 + 3 * a + c], 1u); }
+                        // the bilinear sample from the EXPECTED coordinates, unpacked (same loads: clamped floor, two 8-byte taps)
+                        const float xf = floorf(ex), yf = floorf(ey);
+                        const int x0 = (int)__builtin_amdgcn_fmed3f(xf, -2.0f, (float)W), y0 = (int)__builtin_amdgcn_fmed3f(yf, -2.0f, (float)H);
+                        const float* q = img + (size_t)(y0 + kGrPadY) * WP + (x0 + kGrPadX);
+                        const float t0 = q[0], t1 = q[1], b0 = q[WP], b1 = q[WP + 1];
+                        const float wxl = dg_sub(dg_add(xf, 1.0f), ex), wxh = dg_sub(ex, xf);
+                        const float vyf = dg_add(dg_mul(wxl, t0), dg_mul(wxh, t1)), vyc = dg_add(dg_mul(wxl, b0), dg_mul(wxh, b1));
+                        const float ev = dg_add(dg_mul(dg_sub(dg_add(yf, 1.0f), ey), vyf), dg_mul(dg_sub(ey, yf), vyc));
+                        if (!dg_ne(ix, ex) && !dg_ne(iy, ey) && dg_ne(v, ev)) dg_record(2, ex, ey, t0, t1, b0, b1, v, ev);
+                    }
+#endif
                 }
         } else {
 #pragma unroll
@@ -172,6 +216,22 @@ __global__ __launch_bounds__(256) ASR_KFWD_ATTR void sr_forward_residual_kernel(
         trv = Tq(0, 1, wxl1, wxh1, wyl0, wyh0);
         bl = Tq(1, 0, wxl0, wxh0, wyl1, wyh1);
         br = Tq(1, 1, wxl1, wxh1, wyl1, wyh1);
+#ifdef ASR_DIAG_KFWD_CHECK
+        {
+            auto eTq = [&](int a, int c, float jx, float fxx, float jy, float fyy) -> float {
+                const float wl = dg_sub(dg_add(fxx, 1.0f), jx), wh = dg_sub(jx, fxx), yl = dg_sub(dg_add(fyy, 1.0f), jy), yh = dg_sub(jy, fyy);
+                const float vf = dg_add(dg_mul(wl, rv[a][c]), dg_mul(wh, rv[a][c + 1]));
+                const float vc = dg_add(dg_mul(wl, rv[a + 1][c]), dg_mul(wh, rv[a + 1][c + 1]));
+                return dg_add(dg_mul(yl, vf), dg_mul(yh, vc));
+            };
+            const float e0 = eTq(0, 0, jx0, fx0, jy0, fy0), e1 = eTq(0, 1, jx1, fx1, jy0, fy0), e2 = eTq(1, 0, jx0, fx0, jy1, fy1),
+                        e3 = eTq(1, 1, jx1, fx1, jy1, fy1);
+            if (dg_ne(tl, e0)) dg_record(3, jx0, jy0, rv[0][0], rv[0][1], rv[1][0], rv[1][1], tl, e0);
+            if (dg_ne(trv, e1)) dg_record(3, jx1, jy0, rv[0][1], rv[0][2], rv[1][1], rv[1][2], trv, e1);
+            if (dg_ne(bl, e2)) dg_record(3, jx0, jy1, rv[1][0], rv[1][1], rv[2][0], rv[2][1], bl, e2);
+            if (dg_ne(br, e3)) dg_record(3, jx1, jy1, rv[1][1], rv[1][2], rv[2][1], rv[2][2], br, e3);
+        }
+#endif
     } else {
         tl = T(y0, x0); trv = T(y0, x0 + 1);
         bl = T(y0 + 1, x0); br = T(y0 + 1, x0 + 1);
@@ -181,6 +241,13 @@ __global__ __launch_bounds__(256) ASR_KFWD_ATTR void sr_forward_residual_kernel(
     const float dval = top + (bot - top) * 0.5f;
     const int64_t o = ((int64_t)bn * d.h + i) * d.w + j;
     resid[o] = dval - y[o];
+#ifdef ASR_DIAG_KFWD_CHECK
+    {
+        const float et = dg_add(tl, dg_mul(dg_sub(trv, tl), 0.5f)), eb = dg_add(bl, dg_mul(dg_sub(br, bl), 0.5f));
+        const float ed = dg_add(et, dg_mul(dg_sub(eb, et), 0.5f));
+        if (dg_ne(dval, ed)) dg_record(4, tl, trv, bl, br, top, bot, dval, ed);
+    }
+#endif
 }
 
 // ---- K_bwd --------------------------------------------------------------------------------
@@ -1083,3 +1150,15 @@ extern "C" int asr_realign_max_mean_f32(const float* y, float* out_max, float* o
                                         asr_stream_t stream) {
     return realign_common(2, y, out_max, out_mean, trans_tf, rot_tf, batch, n, H, W, h, w, stream);
 }
+
+#ifdef ASR_DIAG_KFWD_CHECK
+// diag builds only: copy out (and clear) K_fwd's self-check counters [128] and records [16][12]
+extern "C" int asr_diag_kfwd_read(unsigned* counters, float* records) {
+    ASR_HIP_CHECK(hipDeviceSynchronize());
+    ASR_HIP_CHECK(hipMemcpyFromSymbol(counters, HIP_SYMBOL(g_kfwd_cnt), sizeof(unsigned) * 128));
+    ASR_HIP_CHECK(hipMemcpyFromSymbol(records, HIP_SYMBOL(g_kfwd_rec), sizeof(float) * 16 * 12));
+    static unsigned zero[128];
+    ASR_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_kfwd_cnt), zero, sizeof(zero)));
+    return ASR_OK;
+}
+#endif

@@ -67,6 +67,8 @@ OBJECTS = {
     "dwconv_skip2": ("dwconv.hip", ["-DASR_DIAG_DW=2"]),      # f32 store instead of split + lane trade
     "dwconv_skip4": ("dwconv.hip", ["-DASR_DIAG_DW=4"]),      # one load per row instead of three
     "dwconv_skip7": ("dwconv.hip", ["-DASR_DIAG_DW=7"]),      # all three: a copy with the kernel's skeleton
+    # K_fwd with packed-f32 AND a stage-by-stage self-check against unpacked arithmetic (tools/diag_kfwd_selfcheck.py)
+    "sr_pk_check": ("sr.hip", FP + ["-DASR_DIAG_KFWD_CHECK"]),
     "sr_pk_v112": ("sr.hip", FP + ["-DASR_DIAG_KFWD_TOP_VGPR=111"]),
     "sr_nopk_v96": ("sr.hip", FP + B.NO_PK_F32 + ["-DASR_DIAG_KFWD_TOP_VGPR=95"]),     # the product's K_fwd, allocation raised from 64 to 96
 }
@@ -87,6 +89,7 @@ LIBS = {
     "pk_sepconv_pk_v216": {"sr": "sr_pk", "sepconv": "sepconv_pk_v216"},
     "pk112": {"sr": "sr_pk_v112"},
     "dwclamped": {"dwconv": "dwconv_clamped"},
+    "pk_check": {"sr": "sr_pk_check"},
     "dw_skip1": {"dwconv": "dwconv_skip1"}, "dw_skip2": {"dwconv": "dwconv_skip2"}, "dw_skip4": {"dwconv": "dwconv_skip4"},
     "dw_skip7": {"dwconv": "dwconv_skip7"},
     # fourth matrix: which PART of the stem makes it an aggressor (victim = K_fwd with packed-f32)
