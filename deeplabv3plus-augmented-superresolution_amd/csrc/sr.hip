@@ -51,6 +51,15 @@ __global__ __launch_bounds__(256) void sr_init_kernel(const float* __restrict__ 
 // asr_tf_bilinear over a bounds-checked reader -> bit-identical.
 // 32 border columns = one 128-byte line: every row's payload then starts on a line (with 4 columns -- enough for the taps --
 // each 256-byte row segment a wave writes straddled three lines: K_gt + K_bwd 68 -> 62 us per iteration at N = 100).
+#if defined(ASR_DIAG_KFWD_CHECK) || defined(ASR_DIAG_KFWD_NOPK)
+// unpacked arithmetic written out in asm (diagnostic builds only): the compiler can neither pair nor reorder these
+__device__ __forceinline__ float dg_mul(float x, float y) { float z; asm volatile("v_mul_f32 %0, %1, %2" : "=v"(z) : "v"(x), "v"(y)); return z; }
+__device__ __forceinline__ float dg_add(float x, float y) { float z; asm volatile("v_add_f32 %0, %1, %2" : "=v"(z) : "v"(x), "v"(y)); return z; }
+__device__ __forceinline__ float dg_sub(float x, float y) { float z; asm volatile("v_sub_f32 %0, %1, %2" : "=v"(z) : "v"(x), "v"(y)); return z; }
+#endif
+#ifndef ASR_DIAG_KFWD_NOPK
+#define ASR_DIAG_KFWD_NOPK 0      // bits: 1 the coordinate map, 2 the bilinear sample, 4 the translate blend + D -- that stage of K_fwd in unpacked asm
+#endif
 constexpr int kGrPadX = 32, kGrPadY = 2;
 __host__ __device__ inline size_t sr_gr_plane_elems(int H, int W) { return (size_t)(H + 2 * kGrPadY) * (size_t)(W + 2 * kGrPadX); }
 typedef float asr_f2u __attribute__((ext_vector_type(2), aligned(4)));
@@ -70,17 +79,32 @@ __device__ __forceinline__ float sr_bilinear_bordered(const float* __restrict__ 
     const char* const base_next = base + WP * 4;               // the next row through a second SCALAR base, not a lane add
     const asr_f2u top = *reinterpret_cast<const asr_f2u*>(base + off);
     const asr_f2u bot = *reinterpret_cast<const asr_f2u*>(base_next + off);
+#ifdef ASR_DIAG_KFWD_WAIT      // diagnostic: every sample waits for its own two loads before any arithmetic on them (no loads in flight
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // of THIS wave while its packed ops execute)
+#endif
+#if ASR_DIAG_KFWD_NOPK & 2
+    const float wxl = dg_sub(dg_add(xf, 1.0f), ix), wxh = dg_sub(ix, xf);
+    const float vyf = dg_add(dg_mul(wxl, top.x), dg_mul(wxh, top.y));
+    const float vyc = dg_add(dg_mul(wxl, bot.x), dg_mul(wxh, bot.y));
+    return dg_add(dg_mul(dg_sub(dg_add(yf, 1.0f), iy), vyf), dg_mul(dg_sub(iy, yf), vyc));
+#else
     const float wxl = (xf + 1.0f) - ix, wxh = ix - xf;
     const float vyf = wxl * top.x + wxh * top.y;
     const float vyc = wxl * bot.x + wxh * bot.y;
     return ((yf + 1.0f) - iy) * vyf + (iy - yf) * vyc;
+#endif
 }
 
 // asr_tf_map for a transform known to be affine (c0 == c1 == 0): the same two expressions without the (uniform) branch
 // on the projective terms -- a branch inside a sampling loop makes the compiler wait for each sample's loads in turn.
 __device__ __forceinline__ void sr_map_affine(const AsrTf8& t, float x, float y, float& ix, float& iy) {
+#if ASR_DIAG_KFWD_NOPK & 1
+    ix = dg_add(dg_add(dg_mul(t.a0, x), dg_mul(t.a1, y)), t.a2);
+    iy = dg_add(dg_add(dg_mul(t.b0, x), dg_mul(t.b1, y)), t.b2);
+#else
     ix = t.a0 * x + t.a1 * y + t.a2;
     iy = t.b0 * x + t.b1 * y + t.b2;
+#endif
 }
 
 #ifdef ASR_DIAG_KFWD_CHECK
@@ -92,9 +116,6 @@ __device__ __forceinline__ void sr_map_affine(const AsrTf8& t, float x, float y,
 //   records (first 16 mismatches): stage, lane, inputs, got, expected
 __device__ unsigned g_kfwd_cnt[128];
 __device__ float g_kfwd_rec[16][12];
-__device__ __forceinline__ float dg_mul(float x, float y) { float z; asm volatile("v_mul_f32 %0, %1, %2" : "=v"(z) : "v"(x), "v"(y)); return z; }
-__device__ __forceinline__ float dg_add(float x, float y) { float z; asm volatile("v_add_f32 %0, %1, %2" : "=v"(z) : "v"(x), "v"(y)); return z; }
-__device__ __forceinline__ float dg_sub(float x, float y) { float z; asm volatile("v_sub_f32 %0, %1, %2" : "=v"(z) : "v"(x), "v"(y)); return z; }
 __device__ __forceinline__ bool dg_ne(float a, float b) { return __float_as_int(a) != __float_as_int(b); }
 __device__ __forceinline__ void dg_record(int stage, float i0, float i1, float i2, float i3, float i4, float i5, float got, float want) {
     atomicAdd(&g_kfwd_cnt[stage], 1u);
@@ -205,6 +226,15 @@ __global__ __launch_bounds__(256) ASR_KFWD_ATTR void sr_forward_residual_kernel(
 #pragma unroll
                 for (int c = 0; c < 3; ++c) rv[a][c] = rd_rot(cy0 + a, cx0 + c);
         }
+#if ASR_DIAG_KFWD_NOPK & 4
+        const float wxl0 = dg_sub(dg_add(fx0, 1.0f), jx0), wxh0 = dg_sub(jx0, fx0), wxl1 = dg_sub(dg_add(fx1, 1.0f), jx1), wxh1 = dg_sub(jx1, fx1);
+        const float wyl0 = dg_sub(dg_add(fy0, 1.0f), jy0), wyh0 = dg_sub(jy0, fy0), wyl1 = dg_sub(dg_add(fy1, 1.0f), jy1), wyh1 = dg_sub(jy1, fy1);
+        auto Tq = [&](int a, int c, float wxl, float wxh, float wyl, float wyh) -> float {
+            const float vyf = dg_add(dg_mul(wxl, rv[a][c]), dg_mul(wxh, rv[a][c + 1]));
+            const float vyc = dg_add(dg_mul(wxl, rv[a + 1][c]), dg_mul(wxh, rv[a + 1][c + 1]));
+            return dg_add(dg_mul(wyl, vyf), dg_mul(wyh, vyc));
+        };
+#else
         const float wxl0 = (fx0 + 1.0f) - jx0, wxh0 = jx0 - fx0, wxl1 = (fx1 + 1.0f) - jx1, wxh1 = jx1 - fx1;
         const float wyl0 = (fy0 + 1.0f) - jy0, wyh0 = jy0 - fy0, wyl1 = (fy1 + 1.0f) - jy1, wyh1 = jy1 - fy1;
         auto Tq = [&](int a, int c, float wxl, float wxh, float wyl, float wyh) -> float {
@@ -212,6 +242,7 @@ __global__ __launch_bounds__(256) ASR_KFWD_ATTR void sr_forward_residual_kernel(
             const float vyc = wxl * rv[a + 1][c] + wxh * rv[a + 1][c + 1];
             return wyl * vyf + wyh * vyc;
         };
+#endif
         tl = Tq(0, 0, wxl0, wxh0, wyl0, wyh0);
         trv = Tq(0, 1, wxl1, wxh1, wyl0, wyh0);
         bl = Tq(1, 0, wxl0, wxh0, wyl1, wyh1);

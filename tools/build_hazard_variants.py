@@ -69,6 +69,12 @@ OBJECTS = {
     "dwconv_skip7": ("dwconv.hip", ["-DASR_DIAG_DW=7"]),      # all three: a copy with the kernel's skeleton
     # K_fwd with packed-f32 AND a stage-by-stage self-check against unpacked arithmetic (tools/diag_kfwd_selfcheck.py)
     "sr_pk_check": ("sr.hip", FP + ["-DASR_DIAG_KFWD_CHECK"]),
+    "sr_pk_wait": ("sr.hip", FP + ["-DASR_DIAG_KFWD_WAIT"]),
+    # ... and ONE stage of K_fwd written in unpacked asm (bisect of the victim): 1 coordinate map, 2 bilinear sample, 4 translate blend
+    "sr_pk_wait_nopk1": ("sr.hip", FP + ["-DASR_DIAG_KFWD_WAIT", "-DASR_DIAG_KFWD_NOPK=1"]),
+    "sr_pk_wait_nopk2": ("sr.hip", FP + ["-DASR_DIAG_KFWD_WAIT", "-DASR_DIAG_KFWD_NOPK=2"]),
+    "sr_pk_wait_nopk4": ("sr.hip", FP + ["-DASR_DIAG_KFWD_WAIT", "-DASR_DIAG_KFWD_NOPK=4"]),
+    "sr_pk_wait_nopk7": ("sr.hip", FP + ["-DASR_DIAG_KFWD_WAIT", "-DASR_DIAG_KFWD_NOPK=7"]),          # packed-f32, but no load of the wave in flight behind its packed ops
     "sr_pk_v112": ("sr.hip", FP + ["-DASR_DIAG_KFWD_TOP_VGPR=111"]),
     "sr_nopk_v96": ("sr.hip", FP + B.NO_PK_F32 + ["-DASR_DIAG_KFWD_TOP_VGPR=95"]),     # the product's K_fwd, allocation raised from 64 to 96
 }
@@ -90,6 +96,9 @@ LIBS = {
     "pk112": {"sr": "sr_pk_v112"},
     "dwclamped": {"dwconv": "dwconv_clamped"},
     "pk_check": {"sr": "sr_pk_check"},
+    "pk_wait": {"sr": "sr_pk_wait"},
+    "pk_wait_nopk1": {"sr": "sr_pk_wait_nopk1"}, "pk_wait_nopk2": {"sr": "sr_pk_wait_nopk2"}, "pk_wait_nopk4": {"sr": "sr_pk_wait_nopk4"},
+    "pk_wait_nopk7": {"sr": "sr_pk_wait_nopk7"},
     "dw_skip1": {"dwconv": "dwconv_skip1"}, "dw_skip2": {"dwconv": "dwconv_skip2"}, "dw_skip4": {"dwconv": "dwconv_skip4"},
     "dw_skip7": {"dwconv": "dwconv_skip7"},
     # fourth matrix: which PART of the stem makes it an aggressor (victim = K_fwd with packed-f32)

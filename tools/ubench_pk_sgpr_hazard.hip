@@ -27,8 +27,12 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 //   5 pk_mul IN PLACE (dst = src0)                          6 pk_mul in place with the halves of src0 swapped (op_sel:[1,0] op_sel_hi:[0,1])
 //   7 pk_add in place with neg_lo / neg_hi on src1          8 pk_mul with op_sel_hi:[1,0] (low half of src1 for both)
 //   9 a chain of four dependent in-place packed ops (mul, add, mul swapped, add neg)
+//  10 pk_add in place, src1 halves swapped + negated (op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1])   } the two forms that
+//  11 pk_add in place, src0 halves swapped, src1 negated (op_sel:[1,0] op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]) } ONLY the failing
+//  12 K_fwd's weight sequence: (a + 1.0) [op_sel_hi:[1,0] on the constant], then form 10 on it, then form 11       } builds of K_fwd hold
+//  13 form 10 NOT in place
 // alloc_all[base granule 0..63], alloc_bad[base granule]: histogram of VGPR_BASE (units of 8 registers) over all / failing waves
-constexpr int NFORMS = 10;
+constexpr int NFORMS = 14;
 // LOADS: eight 8-byte global loads per lane are in flight (into v60..v75, not otherwise used) while the packed ops execute --
 // K_fwd of the SR solver issues its 18 tap loads and computes the next coordinates behind them.
 template <bool LOADS>
@@ -51,8 +55,8 @@ __global__ __launch_bounds__(256) void victim(const float* __restrict__ src, uns
                 :: "v"(q) : "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "memory");
         }
         asm volatile(
-            "v_mov_b32 v8, %20\n v_mov_b32 v9, %21\n v_mov_b32 v10, %22\n v_mov_b32 v11, %23\n"
-            "v_mov_b32 v84, %20\n v_mov_b32 v85, %21\n v_mov_b32 v86, %22\n v_mov_b32 v87, %23\n"
+            "v_mov_b32 v8, %28\n v_mov_b32 v9, %29\n v_mov_b32 v10, %30\n v_mov_b32 v11, %31\n"
+            "v_mov_b32 v84, %28\n v_mov_b32 v85, %29\n v_mov_b32 v86, %30\n v_mov_b32 v87, %31\n"
             "v_pk_mul_f32 v[12:13], v[8:9], v[10:11]\n"
             "v_pk_mul_f32 v[88:89], v[84:85], v[86:87]\n"
             "v_pk_add_f32 v[90:91], v[84:85], v[86:87]\n"
@@ -82,9 +86,28 @@ __global__ __launch_bounds__(256) void victim(const float* __restrict__ src, uns
             "v_pk_mul_f32 v[88:89], v[88:89], v[86:87] op_sel:[1,0] op_sel_hi:[0,1]\n"
             "v_pk_add_f32 v[88:89], v[88:89], v[86:87] neg_lo:[0,1] neg_hi:[0,1]\n"
             "v_mov_b32 %18, v88\n v_mov_b32 %19, v89\n"
+            // 10: in place, src1 halves swapped and negated
+            "v_mov_b32 v90, v84\n v_mov_b32 v91, v85\n"
+            "v_pk_add_f32 v[90:91], v[90:91], v[86:87] op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n"
+            "v_mov_b32 %20, v90\n v_mov_b32 %21, v91\n"
+            // 11: in place, src0 halves swapped, src1 negated
+            "v_mov_b32 v92, v84\n v_mov_b32 v93, v85\n"
+            "v_pk_add_f32 v[92:93], v[92:93], v[86:87] op_sel:[1,0] op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]\n"
+            "v_mov_b32 %22, v92\n v_mov_b32 %23, v93\n"
+            // 12: K_fwd's weight sequence
+            "v_mov_b32 v94, v86\n v_mov_b32 v95, v87\n"
+            "v_pk_add_f32 v[88:89], v[84:85], 1.0 op_sel_hi:[1,0]\n"
+            "v_pk_add_f32 v[88:89], v[88:89], v[94:95] op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n"
+            "v_pk_add_f32 v[94:95], v[94:95], v[84:85] op_sel:[1,0] op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]\n"
+            "v_add_f32 v88, v88, v94\n v_add_f32 v89, v89, v95\n"
+            "v_mov_b32 %24, v88\n v_mov_b32 %25, v89\n"
+            // 13: form 10 not in place
+            "v_pk_add_f32 v[90:91], v[84:85], v[86:87] op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n"
+            "v_mov_b32 %26, v90\n v_mov_b32 %27, v91\n"
             : "=&v"(r[0][0]), "=&v"(r[0][1]), "=&v"(r[1][0]), "=&v"(r[1][1]), "=&v"(r[2][0]), "=&v"(r[2][1]), "=&v"(r[3][0]), "=&v"(r[3][1]),
               "=&v"(r[4][0]), "=&v"(r[4][1]), "=&v"(r[5][0]), "=&v"(r[5][1]), "=&v"(r[6][0]), "=&v"(r[6][1]), "=&v"(r[7][0]), "=&v"(r[7][1]),
-              "=&v"(r[8][0]), "=&v"(r[8][1]), "=&v"(r[9][0]), "=&v"(r[9][1])
+              "=&v"(r[8][0]), "=&v"(r[8][1]), "=&v"(r[9][0]), "=&v"(r[9][1]), "=&v"(r[10][0]), "=&v"(r[10][1]), "=&v"(r[11][0]), "=&v"(r[11][1]),
+              "=&v"(r[12][0]), "=&v"(r[12][1]), "=&v"(r[13][0]), "=&v"(r[13][1])
             : "v"(a.x), "v"(a.y), "v"(b.x), "v"(b.y)
             : "v8", "v9", "v10", "v11", "v12", "v13", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95",
               "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75");   // (loads may be landing there)
@@ -109,6 +132,15 @@ __global__ __launch_bounds__(256) void victim(const float* __restrict__ src, uns
             float d0 = mul(c1, b.x), d1 = mul(c0, b.y);                   // swapped mul
             e[9][0] = sub(d0, b.x); e[9][1] = sub(d1, b.y);
         }
+        e[10][0] = sub(a.x, b.y); e[10][1] = sub(a.y, b.x);           // lo = src0.lo - src1.hi, hi = src0.hi - src1.lo
+        e[11][0] = sub(a.y, b.x); e[11][1] = sub(a.x, b.y);           // lo = src0.hi - src1.lo, hi = src0.lo - src1.hi
+        {
+            const float p0 = add(a.x, 1.0f), p1 = add(a.y, 1.0f);     // (a + 1)
+            const float q0 = sub(p0, b.y), q1 = sub(p1, b.x);         // form 10 on it with src1 = b
+            const float w0 = sub(b.y, a.x), w1 = sub(b.x, a.y);       // form 11: src0 = b (halves swapped), src1 = a negated
+            e[12][0] = add(q0, w0); e[12][1] = add(q1, w1);
+        }
+        e[13][0] = e[10][0]; e[13][1] = e[10][1];
 #pragma unroll
         for (int f = 0; f < NFORMS; ++f)
             nbad[f] += (__float_as_int(r[f][0]) != __float_as_int(e[f][0])) | (__float_as_int(r[f][1]) != __float_as_int(e[f][1]));
@@ -223,7 +255,7 @@ int main(int argc, char** argv) {
     CK(hipStreamCreateWithFlags(&sb, hipStreamNonBlocking));
     float *src, *sink;
     unsigned* stats;                                            // bad[NFORMS * 64] | alloc_all[64] | alloc_bad[64] | first_bad[18]
-    CK(hipMalloc(&src, 512 * 4)); CK(hipMalloc(&sink, (size_t)4 << 22)); CK(hipMalloc(&stats, 1024 * 4));
+    CK(hipMalloc(&src, 512 * 4)); CK(hipMalloc(&sink, (size_t)4 << 22)); CK(hipMalloc(&stats, 2048 * 4));
     std::vector<float> hs(512);
     for (int i = 0; i < 512; ++i) hs[i] = 0.0137f * i - 1.3f;
     CK(hipMemcpy(src, hs.data(), 2048, hipMemcpyHostToDevice));
@@ -239,10 +271,11 @@ int main(int argc, char** argv) {
     };
     const int naggr = sizeof(aggr) / sizeof(aggr[0]);
     const char* forms[NFORMS] = {"pk_mul v8..", "pk_mul v84..", "pk_add v84..", "pk_fma v84..", "v_mul v84.. (unpacked)", "pk_mul in place", "pk_mul in place, src0 halves swapped",
-                                 "pk_add in place, neg src1", "pk_mul op_sel_hi:[1,0]", "chain of 4 in-place packed ops"};
+                                 "pk_add in place, neg src1", "pk_mul op_sel_hi:[1,0]", "chain of 4 in-place packed ops",
+                                 "pk_add in place, src1 swapped + neg", "pk_add in place, src0 swapped, src1 neg", "K_fwd weight sequence", "pk_add src1 swapped + neg, not in place"};
     for (int with_loads = 0; with_loads < 2; ++with_loads)
     for (int m = -1; m < naggr; ++m) {
-        CK(hipMemset(stats, 0, 1024 * 4));
+        CK(hipMemset(stats, 0, 2048 * 4));
         hipEvent_t e0, e1, v0, v1;
         CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1)); CK(hipEventCreate(&v0)); CK(hipEventCreate(&v1));
         float ms_a = 0.f, ms_v = 0.f;
@@ -263,8 +296,8 @@ int main(int argc, char** argv) {
             if (m >= 0) CK(hipEventElapsedTime(&ms_a, e0, e1));
             CK(hipEventElapsedTime(&ms_v, v0, v1));
         }
-        unsigned h[1024];
-        CK(hipMemcpy(h, stats, 4096, hipMemcpyDeviceToHost));
+        unsigned h[2048];
+        CK(hipMemcpy(h, stats, 8192, hipMemcpyDeviceToHost));
         const int A0 = NFORMS * 64, B0 = A0 + 64, F0 = A0 + 128;
         printf("[victim %s loads in flight] ", with_loads ? "WITH" : "without");
         if (m < 0) printf("no aggressor (victims %.2f ms per 8 launches):\n", ms_v);
