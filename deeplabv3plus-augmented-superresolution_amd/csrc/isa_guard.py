@@ -2,19 +2,21 @@
 
     python isa_guard.py [library]        # prints the violations, exit status 1 if there are any
 
-Why (profiles/r04_hazard_matrix.txt): on MI355X a wave that executes packed-f32 instructions (v_pk_mul_f32 /
-v_pk_add_f32 / v_pk_fma_f32, with scalar OR vector sources) returned garbage in lanes 48-63 of some of them while it shared
-a SIMD with two waves of entry_stem_fused_kernel / sepconv_fused_kernel launched on another stream -- 12 of 12 trials in
-every variant in which the victim fits beside those waves (they take 200 / 208 of the SIMD's 512 vector registers each),
-0 of 12 when it does not fit (aggressor raised to 216 / 256 registers) and 0 of 12 for the same victim kernel at the same
-register allocation without packed-f32 instructions.  The rules:
-  (a) a kernel that can share a SIMD with two 200-register waves -- vector-register allocation <= CORESIDENT_MAX_VGPR = 112 --
-      contains NO packed-f32 instruction (kernel attribute ASR_NO_PK_F32 of asr_common.h, or the NO_PK_F32 flags of build.py);
-  (b) no packed-f32 instruction anywhere takes a scalar-register source (round 3's narrower rule; kept: it costs nothing);
-  (c) MODE (s_setreg) is written only by the kernels listed in MODE_WRITERS;
-  (d) the fused entry-flow kernels (FUSED_KERNELS) allocate at least 200 registers each, which is what makes 112 the bound of (a).
+Why (profiles/r04_hazard_matrix.txt, tools/ubench_pk_opsel_erratum.hip).  On MI355X a packed-f32 instruction
+(v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32) whose LOW result takes the low half of src0 and the HIGH half of a vector-register
+src1 -- VOP3P op_sel = [0,1(,x)], whatever op_sel_hi and the negate modifiers -- returns a wrong result in lanes 48-63 while an
+MFMA instruction of ANOTHER wave is in flight on the same SIMD.  Found in round 3 as SR solves going wrong next to forward
+passes, characterised in round 4: a 16-form microbenchmark beside a bare MFMA loop (the eight forms with op_sel = [0,1] wrong in
+~10 % of the co-resident waves, the other eight -- plain, src0 swapped, both swapped, src1 low half for both, src2 swapped, an
+SGPR src1 -- never), and confirmed on the real kernel: rewriting ONLY those instructions (107 of sr.hip's 2 011 packed ops) in the
+device assembly makes the solver immune, 0 of 12 where the unmodified build moves 12 of 12.  The rules:
+  (1) ERRATUM  no packed-f32 instruction with op_sel[0] = 0, op_sel[1] = 1 and a vector-register src1, in ANY kernel;
+  (2) POLICY   packed-f32 instructions only in the kernels that opted in (ASR_PK_F32 in asr_common.h; PK_KERNELS below): the compiler
+               chooses op_sel by itself, so the set of kernels in which it may do so stays small and reviewed -- in particular none
+               of the second-lane kernels (sr.hip, warp.hip, reduce.hip), where it DID emit the form;
+  (3) MODE (s_setreg) is written only by the kernels listed in MODE_WRITERS.
 csrc/build.py runs this check after every link and tests/test_isa_guard.py runs it on the CPU box, so neither a source edit nor
-a compiler update can bring the forms back unnoticed.
+a compiler update can bring the form back unnoticed.
 
 The device code of a hipcc-linked shared object sits in its .hip_fatbin section as one clang offload bundle per translation
 unit; the gfx950 code objects are cut out of it here and disassembled with llvm-objdump.
@@ -33,18 +35,33 @@ PKG = os.path.dirname(HERE)
 _MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"
 _LLVM_BIN = [os.environ.get("ASR_LLVM_BIN", ""), "/opt/rocm/lib/llvm/bin", "/opt/rocm/llvm/bin"]
 
-# kernels (demangled-name substrings) that may write the MODE register: they switch the f16 overflow clamp on for their
-# saturating split (asr_common.h: asr_enable_f16_saturation)
+# kernels (name substrings) that may write the MODE register: they switch the f16 overflow clamp on for their saturating split
+# (asr_common.h: asr_enable_f16_saturation)
 MODE_WRITERS = ("entry_stem_fused_kernel", "conv3x3_stem_mfma_kernel", "pw_gemm_f16x3_kernel", "sepconv_fused_kernel",
                 "dw_stream_full_kernel", "aspp_dw3_phase_kernel")
-
-# the fused entry-flow kernels keep two waves of >= 200 registers on a SIMD: what fits beside them has at most this many
-FUSED_KERNELS = ("entry_stem_fused_kernel", "sepconv_fused_kernel")
-FUSED_MIN_VGPR = 200                               # ASR_FUSED_MIN_VGPRS of asr_common.h
-CORESIDENT_MAX_VGPR = 512 - 2 * FUSED_MIN_VGPR
+# kernels that carry ASR_PK_F32 (packed-f32 opted in): where it pays -- the streaming depthwise kernels, the ring GEMMs' epilogues, the
+# fused entry-flow kernels, the direct conv stems
+PK_KERNELS = ("dw_stream_full_kernel", "pw_gemm_f16x3_pre_ring", "sepconv_fused_kernel", "entry_stem_fused_kernel",
+              "conv3x3_stem_kernel", "conv3x3_stem_mfma_kernel")
 
 _PK_F32 = re.compile(r"\bv_pk_(mul|add|fma)_f32\b")
 _SGPR_SRC = re.compile(r"(?<![a-z_0-9])(s\[\d+:\d+\]|(s\d+|vcc|exec|ttmp\d+|ttmp\[\d+:\d+\]|m0)\b)")
+_OP_SEL = re.compile(r"\bop_sel:\[([01,]+)\]")
+
+
+def erratum_form(inst):
+    """True for a packed-f32 instruction whose low result reads src0's LOW half and the HIGH half of a VECTOR-register src1
+    (op_sel[0] = 0, op_sel[1] = 1): the form that returns wrong lanes 48-63 beside a co-resident MFMA (module docstring)."""
+    if not _PK_F32.search(inst):
+        return False
+    m = _OP_SEL.search(inst)
+    if not m:
+        return False
+    sel = [int(v) for v in m.group(1).split(",")]
+    if len(sel) < 2 or sel[0] != 0 or sel[1] != 1:
+        return False
+    ops = inst.split(None, 1)[1].split(",")            # dst, src0, src1, ...
+    return len(ops) >= 3 and ops[2].strip().startswith("v[")
 
 
 class ToolMissing(RuntimeError):
@@ -140,42 +157,34 @@ def violations(lib_path=None):
     """[(kernel, instruction, rule)] for the library (default: the product library next to this package)."""
     lib_path = lib_path or os.path.join(PKG, "libasr_hip.so")
     bad = []
-    vgprs = kernel_vgprs(lib_path)
     for kern, insts in disassemble(lib_path).items():
-        if kern not in vgprs:
-            bad.append((kern, "", "no register count in the code object metadata"))
-            continue
-        if any(k in kern for k in FUSED_KERNELS) and vgprs[kern] < FUSED_MIN_VGPR:
-            bad.append((kern, "", f"fused entry-flow kernel with {vgprs[kern]} registers (< {FUSED_MIN_VGPR}): larger kernels would fit beside it"))
-        small = _allocated(vgprs[kern]) <= CORESIDENT_MAX_VGPR
+        opted_in = any(k in kern for k in PK_KERNELS)
         for inst in insts:
-            if _PK_F32.search(inst):
-                if small:
-                    bad.append((kern, inst, f"packed-f32 in a kernel of {vgprs[kern]} registers (fits beside the fused entry-flow kernels)"))
-                elif _SGPR_SRC.search(_sources(inst)):
-                    bad.append((kern, inst, "packed-f32 with a scalar-register source"))
+            if erratum_form(inst):
+                bad.append((kern, inst, "ERRATUM: packed-f32 with op_sel = [0,1] on a vector src1 (wrong lanes 48-63 beside MFMA)"))
+            elif _PK_F32.search(inst) and not opted_in:
+                bad.append((kern, inst, "POLICY: packed-f32 in a kernel that did not opt in (ASR_PK_F32 / PK_KERNELS)"))
             elif inst.startswith("s_setreg") and not any(k in kern for k in MODE_WRITERS):
                 bad.append((kern, inst, "MODE write outside the listed kernels"))
     return bad
 
 
 def summary(lib_path=None):
-    """Counts the guard's rules are about, per library: packed-f32 ops (all / with a scalar source), MODE writers."""
+    """Counts the guard's rules are about, per library."""
     lib_path = lib_path or os.path.join(PKG, "libasr_hip.so")
-    pk = pk_s = 0
-    writers, holders = set(), {}
-    vgprs = kernel_vgprs(lib_path)
+    pk = err = 0
+    writers, holders, forms = set(), set(), {}
     for kern, insts in disassemble(lib_path).items():
         for inst in insts:
             if _PK_F32.search(inst):
                 pk += 1
-                pk_s += bool(_SGPR_SRC.search(_sources(inst)))
-                holders[kern] = vgprs.get(kern)
+                err += erratum_form(inst)
+                holders.add(kern)
+                key = " ".join(re.findall(r"(?:op_sel|op_sel_hi|neg_lo|neg_hi):\[[01,]+\]", inst)) or "(no modifiers)"
+                forms[key] = forms.get(key, 0) + 1
             if inst.startswith("s_setreg"):
                 writers.add(kern)
-    return {"packed_f32": pk, "packed_f32_scalar_source": pk_s, "kernels": len(vgprs),
-            "kernels_with_packed_f32": len(holders),
-            "fewest_registers_of_a_kernel_with_packed_f32": min((v for v in holders.values() if v is not None), default=None),
+    return {"packed_f32": pk, "packed_f32_erratum_form": err, "packed_f32_forms": forms, "kernels_with_packed_f32": sorted(holders),
             "mode_writers": sorted(writers)}
 
 

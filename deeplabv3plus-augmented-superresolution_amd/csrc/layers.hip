@@ -249,8 +249,6 @@ __global__ __launch_bounds__(512) ASR_PK_F32 void entry_stem_fused_kernel(const 
     asr_enable_f16_saturation();                              // the splits below convert with the hardware's f16 clamp
 #ifdef ASR_DIAG_STEM_TOP_VGPR
     ASR_DIAG_TOUCH_VGPR(ASR_DIAG_STEM_TOP_VGPR);
-#else
-    ASR_TOUCH_VGPR(199);                                      // >= ASR_FUSED_MIN_VGPRS (it needs exactly 200 today)
 #endif
     extern __shared__ __attribute__((aligned(16))) char es_lds[];
     char* const T1 = es_lds;

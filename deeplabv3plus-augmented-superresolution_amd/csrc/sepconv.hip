@@ -19,8 +19,8 @@
 
 // 1: the stage-1 split uses the packed saturating conversions of asr_common.h (2.4 - 3 % faster than clamp + convert per
 // value).  Round 3 switched it off because with it (208 instead of 212 registers) a wave of the SR solver fits beside two of
-// this kernel's waves on a SIMD, and the solver's packed-f32 instructions then went wrong; since round 4 no
-// kernel small enough to fit there contains such instructions (csrc/isa_guard.py).
+// this kernel's waves on a SIMD, whose MFMAs then corrupted the solver's op_sel:[0,1] packed-f32 instructions;
+// since round 4 no kernel of the library contains that instruction form (csrc/isa_guard.py).
 #ifndef ASR_SEPCONV_PACKED_SPLIT
 #define ASR_SEPCONV_PACKED_SPLIT 1
 #endif
@@ -63,8 +63,6 @@ __global__ __launch_bounds__(512) ASR_PK_F32 ASR_SEPCONV_ATTR void sepconv_fused
 #endif
 #ifdef ASR_DIAG_SEPCONV_TOP_VGPR
     ASR_DIAG_TOUCH_VGPR(ASR_DIAG_SEPCONV_TOP_VGPR);
-#else
-    ASR_TOUCH_VGPR(199);                                      // >= ASR_FUSED_MIN_VGPRS (the 64-channel instance needs only 180)
 #endif
     constexpr int QUADS = CIN / 4;                            // channel quads: 32 or 16
     constexpr int HALVES = 32 / QUADS;                        // row halves of the tile handled by different thread slots
