@@ -298,7 +298,10 @@ def unit_hashes():
     out = {}
     for src, flags in b.SOURCES:
         h = hashlib.sha256(hdr.digest())
-        h.update(" ".join(b.COMMON + flags).encode())
+        h.update(" ".join(b.COMMON + flags + (["postpass"] if src in getattr(b, "POSTPASS", ()) else [])).encode())
+        if src in getattr(b, "POSTPASS", ()):
+            with open(os.path.join(csrc, "pk_postpass.py"), "rb") as fh:
+                h.update(fh.read())
         with open(os.path.join(csrc, src), "rb") as fh:
             h.update(fh.read())
         out[os.path.splitext(src)[0]] = h.hexdigest()[:16]
