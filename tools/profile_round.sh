@@ -4,7 +4,7 @@
 #                                                       image at a time, kernels never overlap -> per-kernel averages are the
 #                                                       stand-alone durations; --lanes 2: the default, two images in flight)
 #   kernel_stats_cfg2.csv / kernel_stats_cfg4.csv       the same (lanes 1) for BASELINE configs[2] and configs[4]
-#   pmc/summary.json, pmc_cfg4/summary.json             HBM bytes per launch (FETCH_SIZE / WRITE_SIZE in separate passes)
+#   pmc/summary.json, pmc_cfg{2,4}/summary.json         HBM bytes per launch (FETCH_SIZE / WRITE_SIZE in separate passes)
 #   pmc_sq/summary.json                                 matrix-pipe occupancy, wave-cycle split, LDS bank conflicts
 #   bench_default.json.log                              the default bench line (with its configs[2] / configs[4] objects)
 #   csrc.sha256                                         one hash per translation unit (source + headers + flags) these summaries were
@@ -42,8 +42,9 @@ if want stats; then
 fi
 if want pmc; then
   bash tools/pmc_traffic.sh $out/pmc 1 > $out/pmc.log 2>&1; echo "pmc rc=$?"
+  bash tools/pmc_traffic.sh $out/pmc_cfg2 2 > $out/pmc_cfg2.log 2>&1; echo "pmc cfg2 rc=$?"
   bash tools/pmc_traffic.sh $out/pmc_cfg4 4 > $out/pmc_cfg4.log 2>&1; echo "pmc cfg4 rc=$?"
-  rm -rf $out/pmc/FETCH_SIZE $out/pmc/WRITE_SIZE $out/pmc_cfg4/FETCH_SIZE $out/pmc_cfg4/WRITE_SIZE
+  rm -rf $out/pmc/FETCH_SIZE $out/pmc/WRITE_SIZE $out/pmc_cfg2/FETCH_SIZE $out/pmc_cfg2/WRITE_SIZE $out/pmc_cfg4/FETCH_SIZE $out/pmc_cfg4/WRITE_SIZE
 fi
 if want sq; then
   bash tools/pmc_sq.sh $out/pmc_sq 1 > $out/pmc_sq.log 2>&1; echo "sq rc=$?"
