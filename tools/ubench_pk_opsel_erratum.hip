@@ -17,7 +17,7 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 
-constexpr int NFORMS = 16;
+constexpr int NFORMS = 21;
 static const char* kForms[NFORMS] = {
     "pk_add plain (control)",
     "pk_add src1 swapped            op_sel:[0,1] op_sel_hi:[1,0]",
@@ -35,6 +35,11 @@ static const char* kForms[NFORMS] = {
     "pk_add src0 swapped            op_sel:[1,0] op_sel_hi:[0,1]",
     "pk_mul src0 swapped            op_sel:[1,0] op_sel_hi:[0,1]",
     "pk_fma src2 swapped            op_sel:[0,0,1] op_sel_hi:[1,1,0]",
+    "v_pk_mov_b32 op_sel:[0,1]      (low = src0.lo, high = src1.hi)",
+    "v_pk_mov_b32 op_sel:[1,0]      (low = src0.hi, high = src1.lo)",
+    "v_pk_mov_b32 op_sel:[1,1]",
+    "v_pk_add_f16 src1 swapped      op_sel:[0,1] op_sel_hi:[1,0]   (packed f16: halves are 16-bit)",
+    "v_pk_fma_f32 op_sel:[0,1,1] op_sel_hi:[1,0,0]   (src1 AND src2 swapped)",
 };
 
 // one form: v84:85 = a, v86:87 = b, v88:89 = c (fma addend / scratch), result in v90:91
@@ -93,6 +98,21 @@ __global__ __launch_bounds__(256) void victim(const float* __restrict__ src, uns
         e[14][0] = mul(a.y, b.x); e[14][1] = mul(a.x, b.y);
         FORM("v_pk_fma_f32 v[90:91], v[84:85], v[86:87], v[88:89] op_sel:[0,0,1] op_sel_hi:[1,1,0]", r[15][0], r[15][1]);
         e[15][0] = fma(a.x, b.x, cy); e[15][1] = fma(a.y, b.y, cx);
+        FORM("v_pk_mov_b32 v[90:91], v[84:85], v[86:87] op_sel:[0,1]", r[16][0], r[16][1]);
+        e[16][0] = a.x; e[16][1] = b.y;
+        FORM("v_pk_mov_b32 v[90:91], v[84:85], v[86:87] op_sel:[1,0]", r[17][0], r[17][1]);
+        e[17][0] = a.y; e[17][1] = b.x;
+        FORM("v_pk_mov_b32 v[90:91], v[84:85], v[86:87] op_sel:[1,1]", r[18][0], r[18][1]);
+        e[18][0] = a.y; e[18][1] = b.y;
+        {   // packed f16 add on the low dwords: v90 = {lo: a.lo16 + b.hi16, hi: a.hi16 + b.lo16}; compared with the unswapped add of b rotated
+            float rr, ee;
+            asm volatile("v_mov_b32 v84, %2\n v_mov_b32 v86, %3\n v_pk_add_f16 v90, v84, v86 op_sel:[0,1] op_sel_hi:[1,0]\n v_mov_b32 %0, v90\n"
+                         "v_alignbit_b32 v87, v86, v86, 16\n v_pk_add_f16 v91, v84, v87\n v_mov_b32 %1, v91\n"
+                         : "=&v"(rr), "=&v"(ee) : "v"(a.x), "v"(b.x) : "v84", "v86", "v87", "v90", "v91");
+            r[19][0] = rr; r[19][1] = 0.f; e[19][0] = ee; e[19][1] = 0.f;
+        }
+        FORM("v_pk_fma_f32 v[90:91], v[84:85], v[86:87], v[88:89] op_sel:[0,1,1] op_sel_hi:[1,0,0]", r[20][0], r[20][1]);
+        e[20][0] = fma(a.x, b.y, cy); e[20][1] = fma(a.y, b.x, cx);
 #pragma unroll
         for (int f = 0; f < NFORMS; ++f)
             nbad[f] += (__float_as_int(r[f][0]) != __float_as_int(e[f][0])) | (__float_as_int(r[f][1]) != __float_as_int(e[f][1]));
