@@ -247,3 +247,36 @@ def test_weights_merge_by_name_skips_mismatches():
     mob = W.make_synthetic_weights(7, 21, backbone="mobilenet")
     _m, sk = W.merge_by_name(mob, ckpt)
     assert W.loaded_fraction(mob, sk) < 0.2
+
+
+def test_bench_quotes_pmc_traffic_per_config_and_per_translation_unit(tmp_path, monkeypatch):
+    """bench.rooflines: `traffic` comes from the PMC summary of THE SAME config (r*_pmc_traffic.json for configs[1],
+    r*_pmc_traffic_cfg<N>.json for configs[N]; none -> null), and only while the kernel family's translation unit is unchanged
+    since the summary was taken (round 3 pasted the configs[1] figure into configs[4]'s line and stamped all units with one hash)."""
+    import json
+    import bench
+    prof_dir = tmp_path / "profiles"
+    prof_dir.mkdir()
+    entry = lambda b: {"hbm_bytes_per_launch": b, "launches_sampled": 4}
+    (prof_dir / "r09_pmc_traffic.json").write_text(json.dumps({"pw_gemm_f16x3_pre_ring_kernel": entry(1000), "dw_stream_full_kernel<1>": entry(10)}))
+    (prof_dir / "r09_pmc_traffic_cfg4.json").write_text(json.dumps({"pw_gemm_f16x3_pre_ring_kernel": entry(4000), "dw_stream_full_kernel<1>": entry(40)}))
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    prof = {"pw16": [10.0, 1e12, 8e8, 10], "dw": [5.0, 1e9, 6e8, 5]}
+    units = {u: "h" for u in ("gemm", "dwconv", "sepconv", "layers", "sr")}
+    fresh = {"units": units, "profiled_units": units, "profiled_at_commit": "abc", "current": {u: True for u in units}}
+    assert bench.rooflines(dict(prof), fresh, 1)["roofline"]["traffic"] == 1000
+    assert bench.rooflines(dict(prof), fresh, 4)["roofline"]["traffic"] == 4000
+    r2 = bench.rooflines(dict(prof), fresh, 2)                                  # no summary for configs[2]
+    assert r2["roofline"]["traffic"] is None and "no PMC summary for configs[2]" in r2["roofline"]["traffic_note"]
+    stale = dict(fresh, current=dict(fresh["current"], gemm=False))           # gemm.hip changed since: its counters are not quoted ...
+    rs = bench.rooflines(dict(prof), stale, 1)
+    assert rs["roofline"]["traffic"] is None and "another build of gemm.hip" in rs["roofline"]["traffic_note"]
+    assert rs["roofline_depthwise"]["traffic"] == 10                            # ... the depthwise unit's still are
+
+
+def test_bench_unit_hashes_cover_sources_headers_and_flags():
+    import bench
+    h = bench.unit_hashes()
+    assert set(h) == {"core", "warp", "sr", "reduce", "gemm", "dwconv", "layers", "sepconv"} and len(set(h.values())) == len(h)
+    p = bench.profile_provenance()
+    assert set(p["current"]) == set(h) and all(isinstance(v, bool) for v in p["current"].values())
