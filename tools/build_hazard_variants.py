@@ -77,6 +77,7 @@ OBJECTS = {
     "sr_pk_wait_nopk7": ("sr.hip", FP + ["-DASR_DIAG_KFWD_WAIT", "-DASR_DIAG_KFWD_NOPK=7"]),          # packed-f32, but no load of the wave in flight behind its packed ops
     "gemm_nowalk": ("gemm.hip", ["-DASR_PERSISTENT_WALK=0"]),          # A/B: every pre-split GEMM launch on the one-tile kernel (round 3's product)
     "sepconv_clamped": ("sepconv.hip", ["-DASR_SEPCONV_PACKED_SPLIT=0"]),
+    "dwconv_nont": ("dwconv.hip", ["-DASR_DW_NT=0"]),                 # A/B: ordinary (cached) output stores in the depthwise kernels
     "sr_pk_v112": ("sr.hip", FP + ["-DASR_DIAG_KFWD_TOP_VGPR=111"]),
     "sr_nopk_v96": ("sr.hip", FP + B.NO_PK_F32 + ["-DASR_DIAG_KFWD_TOP_VGPR=95"]),     # the product's K_fwd, allocation raised from 64 to 96
 }
@@ -97,6 +98,7 @@ LIBS = {
     "pk_sepconv_pk_v216": {"sr": "sr_pk", "sepconv": "sepconv_pk_v216"},
     "pk112": {"sr": "sr_pk_v112"},
     "dwclamped": {"dwconv": "dwconv_clamped"},
+    "dw_nont": {"dwconv": "dwconv_nont"},
     "nowalk": {"gemm": "gemm_nowalk"}, "sepconv_clamped": {"sepconv": "sepconv_clamped"},
     "pk_check": {"sr": "sr_pk_check"},
     "pk_wait": {"sr": "sr_pk_wait"},
